@@ -1,0 +1,168 @@
+/* labrador_ldpc_hip.h -- C ABI of liblabrador_ldpc_hip.so, the MI355X (gfx950) min-sum decoder.
+ *
+ * Drop-in boundary for the decode_ms path of adamgreig/labrador-ldpc.  The first part mirrors
+ * the reference's C API symbol for symbol (reference: capi/include/labrador_ldpc.h,
+ * implemented in capi/src/lib.rs); the second part adds the batched entry points the GPU
+ * path sits behind.  All paths below are relative to the reference repository.
+ *
+ * Conventions kept from the reference (capi/README.md:84-101, src/lib.rs:15-17):
+ *   - the caller owns every buffer; lengths are implied by `code`, never passed;
+ *   - packed bit buffers are MSB-first inside each byte (src/decoder.rs:459, :490, :506);
+ *   - functions are re-entrant; concurrent calls on disjoint buffers are safe.
+ * Differences, all deliberate:
+ *   - an out-of-range `code` is undefined behaviour in the reference (it is the Rust enum
+ *     itself, src/codes/mod.rs:37-66); here size queries return 0, decoders return false /
+ *     a negative status and write nothing;
+ *   - decode_ms runs on the GPU.  If no usable HIP device or kernel is available the
+ *     decoders FAIL (false / negative status, message via labrador_ldpc_hip_last_error());
+ *     there is no CPU fallback for the hot path;
+ *   - the `working` / `working_u8` arguments of the single-codeword decoders are accepted
+ *     for source compatibility and not touched (all message state lives in GPU registers/LDS).
+ */
+#ifndef LABRADOR_LDPC_HIP_H
+#define LABRADOR_LDPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* capi/include/labrador_ldpc.h:19-29 == #[repr(C)] enum LDPCCode, src/codes/mod.rs:37-66 */
+enum labrador_ldpc_code {
+    LABRADOR_LDPC_CODE_TC128    = 0,
+    LABRADOR_LDPC_CODE_TC256    = 1,
+    LABRADOR_LDPC_CODE_TC512    = 2,
+    LABRADOR_LDPC_CODE_TM1280   = 3,
+    LABRADOR_LDPC_CODE_TM1536   = 4,
+    LABRADOR_LDPC_CODE_TM2048   = 5,
+    LABRADOR_LDPC_CODE_TM5120   = 6,
+    LABRADOR_LDPC_CODE_TM6144   = 7,
+    LABRADOR_LDPC_CODE_TM8192   = 8,
+};
+
+/* ======================================================================================
+ * Part 1 -- the reference's 21 symbols, same names, signatures and meaning.
+ * ====================================================================================== */
+
+/* capi/include/labrador_ldpc.h:118, :121  (capi/src/lib.rs:15-23) */
+size_t labrador_ldpc_code_n(enum labrador_ldpc_code code);
+size_t labrador_ldpc_code_k(enum labrador_ldpc_code code);
+
+/* capi/include/labrador_ldpc.h:124-135  (capi/src/lib.rs:48-66; src/decoder.rs:93-116) */
+size_t labrador_ldpc_bf_working_len(enum labrador_ldpc_code code);
+size_t labrador_ldpc_ms_working_u8_len(enum labrador_ldpc_code code);
+size_t labrador_ldpc_ms_working_len(enum labrador_ldpc_code code);
+size_t labrador_ldpc_output_len(enum labrador_ldpc_code code);
+
+/* capi/include/labrador_ldpc.h:143, :151-152  (capi/src/lib.rs:25-46; src/encoder.rs:293-315).
+ * Host-side systematic encoder: first k/8 bytes are data, the rest is written with parity. */
+void labrador_ldpc_encode(enum labrador_ldpc_code code, uint8_t *codeword);
+void labrador_ldpc_copy_encode(enum labrador_ldpc_code code, const uint8_t *data, uint8_t *codeword);
+
+/* capi/include/labrador_ldpc.h:167-170  (capi/src/lib.rs:68-81; src/decoder.rs:243-301).
+ * Bit-flipping decoder: outside this build's hot path.  The symbol
+ * is exported so that existing callers link; it always returns false and sets the error
+ * string to "decode_bf: not implemented". */
+bool labrador_ldpc_decode_bf(enum labrador_ldpc_code code, const uint8_t *input, uint8_t *output,
+                             uint8_t *working, size_t max_iters, size_t *iters_run);
+
+/* capi/include/labrador_ldpc.h:193-208  (capi/src/lib.rs:83-127; src/decoder.rs:347-475).
+ * One codeword, host pointers; runs the same kernel as the batched calls with batch = 1.
+ * `llrs` n entries, `output` output_len bytes, `iters_run` may be NULL. */
+bool labrador_ldpc_decode_ms_i8 (enum labrador_ldpc_code code, const int8_t  *llrs, uint8_t *output,
+                                 int8_t  *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
+bool labrador_ldpc_decode_ms_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output,
+                                 int16_t *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
+bool labrador_ldpc_decode_ms_f32(enum labrador_ldpc_code code, const float   *llrs, uint8_t *output,
+                                 float   *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
+bool labrador_ldpc_decode_ms_f64(enum labrador_ldpc_code code, const double  *llrs, uint8_t *output,
+                                 double  *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
+
+/* capi/include/labrador_ldpc.h:219-226  (capi/src/lib.rs:129-153; src/decoder.rs:484-493) */
+void labrador_ldpc_hard_to_llrs_i8 (enum labrador_ldpc_code code, const uint8_t *input, int8_t  *llrs);
+void labrador_ldpc_hard_to_llrs_i16(enum labrador_ldpc_code code, const uint8_t *input, int16_t *llrs);
+void labrador_ldpc_hard_to_llrs_f32(enum labrador_ldpc_code code, const uint8_t *input, float   *llrs);
+void labrador_ldpc_hard_to_llrs_f64(enum labrador_ldpc_code code, const uint8_t *input, double  *llrs);
+
+/* capi/include/labrador_ldpc.h:237-244  (capi/src/lib.rs:155-179; src/decoder.rs:498-509) */
+void labrador_ldpc_llrs_to_hard_i8 (enum labrador_ldpc_code code, const int8_t  *llrs, uint8_t *output);
+void labrador_ldpc_llrs_to_hard_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output);
+void labrador_ldpc_llrs_to_hard_f32(enum labrador_ldpc_code code, const float   *llrs, uint8_t *output);
+void labrador_ldpc_llrs_to_hard_f64(enum labrador_ldpc_code code, const double  *llrs, uint8_t *output);
+
+/* ======================================================================================
+ * Part 2 -- batched GPU entry points (no counterpart in the reference; what a caller that
+ * loops over labrador_ldpc_decode_ms_* per frame, e.g. perftest/src/main.rs:9-29, moves to).
+ * ====================================================================================== */
+
+/* status codes */
+#define LABRADOR_LDPC_HIP_OK            0
+#define LABRADOR_LDPC_HIP_EINVAL      (-1)   /* bad code / NULL pointer / misaligned buffer */
+#define LABRADOR_LDPC_HIP_ENODEV      (-2)   /* no HIP device, or the device is not gfx950 */
+#define LABRADOR_LDPC_HIP_ERUNTIME    (-3)   /* a HIP runtime call failed */
+#define LABRADOR_LDPC_HIP_EUNSUPPORTED (-4)  /* valid request this build has no kernel for */
+
+#define LABRADOR_LDPC_HIP_MEM_HOST    0      /* buffers are host memory; the call stages them */
+#define LABRADOR_LDPC_HIP_MEM_DEVICE  1      /* buffers are device memory resident on `device` */
+
+struct labrador_ldpc_hip_opts {
+    int   device;     /* HIP device ordinal; -1 = the calling thread's current device */
+    int   memory;     /* LABRADOR_LDPC_HIP_MEM_HOST or _DEVICE */
+    void *stream;     /* hipStream_t to launch on; NULL = the default stream.  With MEM_DEVICE
+                         the call only enqueues work and returns (asynchronous); with MEM_HOST
+                         it returns after the results are in the host buffers. */
+    int   variant;    /* kernel variant; 0 = the tuned default (others: see DESIGN.md) */
+};
+
+/* Decode `batch` independent frames.
+ *   llrs    [batch][n]            row-major, n = labrador_ldpc_code_n(code)
+ *   output  [batch][output_len]   hard bits incl. punctured parity, MSB first
+ *   iters   [batch]               0-based index of the converging iteration, or max_iters
+ *   success [batch]               1 if all parity checks were satisfied, else 0
+ * Per frame the three results equal what labrador_ldpc_decode_ms_* returns for that frame.
+ * `opts` may be NULL (host memory, current device, default stream).  With MEM_DEVICE,
+ * `output` must be 8-byte aligned.  Returns a status code. */
+int labrador_ldpc_decode_ms_batch_f32(enum labrador_ldpc_code code, const float *llrs, uint8_t *output,
+                                      uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_decode_ms_batch_i8 (enum labrador_ldpc_code code, const int8_t *llrs, uint8_t *output,
+                                      uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output,
+                                      uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts);
+
+/* Synthetic AWGN frames on the device (harness side of the path; what perftest's ms_trial does
+ * per frame at perftest/src/main.rs:10-18, batched): frame f takes codeword (f mod pool) of
+ * `codewords` ([pool][n/8] bytes, MSB first), maps bit b to 1-2b, adds sigma*N(0,1) from a
+ * counter-based generator keyed by (seed, f, sample), and writes
+ *   f32: the sample itself;   i8: clamp(round(scale*sample), -lim, lim).
+ * All pointers are DEVICE memory (opts->memory is ignored); asynchronous on opts->stream. */
+int labrador_ldpc_hip_awgn_f32(enum labrador_ldpc_code code, const uint8_t *codewords, size_t pool,
+                               float *llrs, size_t batch, float sigma, uint64_t seed,
+                               const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_hip_awgn_i8 (enum labrador_ldpc_code code, const uint8_t *codewords, size_t pool,
+                               int8_t *llrs, size_t batch, float sigma, float scale, int lim,
+                               uint64_t seed, const struct labrador_ldpc_hip_opts *opts);
+
+/* Edge stream CRC of this library's own code tables, computed like the reference's
+ * test_iter_parity (src/codes/mod.rs:508-533).  Lets a test pin the tables the kernels are
+ * generated from against the reference's nine known answers without a GPU. */
+uint32_t labrador_ldpc_hip_edge_crc(enum labrador_ldpc_code code);
+
+/* Number of HIP devices usable by this library (gfx950 only); 0 if none. Never fails. */
+int labrador_ldpc_hip_device_count(void);
+
+/* Human-readable description of the calling thread's last failure ("" if none). */
+const char *labrador_ldpc_hip_last_error(void);
+
+/* Library version string. */
+const char *labrador_ldpc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LABRADOR_LDPC_HIP_H */

@@ -1,0 +1,302 @@
+"""labrador_ldpc_amd -- MI355X (gfx950) batched min-sum LDPC decoder behind labrador-ldpc's API.
+
+Host-side mirror of the reference crate's `LDPCCode` surface for the decode_ms path
+(reference: src/codes/mod.rs:365-441 accessors, src/decoder.rs:88-116 sizes, :347-475
+decode_ms, :484-509 LLR helpers, src/encoder.rs:293-315 encode/copy_encode), implemented as a
+thin ctypes binding over the C ABI of ``liblabrador_ldpc_hip.so`` (include/labrador_ldpc_hip.h).
+
+The library is required: importing this package without the built ``.so`` raises, and the
+decoders raise ``LdpcHipError`` when no gfx950 device is usable.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+__all__ = ["LDPCCode", "LdpcHipError", "lib", "device_count", "last_error", "HipOpts", "LIB_PATH"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblabrador_ldpc_hip.so")
+
+
+class LdpcHipError(RuntimeError):
+    """A call into liblabrador_ldpc_hip.so failed (status < 0)."""
+
+
+class HipOpts(ctypes.Structure):
+    """struct labrador_ldpc_hip_opts (include/labrador_ldpc_hip.h)."""
+
+    _fields_ = [("device", ctypes.c_int), ("memory", ctypes.c_int),
+                ("stream", ctypes.c_void_p), ("variant", ctypes.c_int)]
+
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_c = ctypes
+_sz, _vp, _int = _c.c_size_t, _c.c_void_p, _c.c_int
+_optp = _c.POINTER(HipOpts)
+
+# every symbol include/labrador_ldpc_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "labrador_ldpc_code_n": (_sz, [_int]),
+    "labrador_ldpc_code_k": (_sz, [_int]),
+    "labrador_ldpc_bf_working_len": (_sz, [_int]),
+    "labrador_ldpc_ms_working_u8_len": (_sz, [_int]),
+    "labrador_ldpc_ms_working_len": (_sz, [_int]),
+    "labrador_ldpc_output_len": (_sz, [_int]),
+    "labrador_ldpc_encode": (None, [_int, _vp]),
+    "labrador_ldpc_copy_encode": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_decode_bf": (_c.c_bool, [_int, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
+    "labrador_ldpc_decode_ms_i8": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
+    "labrador_ldpc_decode_ms_i16": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
+    "labrador_ldpc_decode_ms_f32": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
+    "labrador_ldpc_decode_ms_f64": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
+    "labrador_ldpc_hard_to_llrs_i8": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_hard_to_llrs_i16": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_hard_to_llrs_f32": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_hard_to_llrs_f64": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_llrs_to_hard_i8": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_llrs_to_hard_i16": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_llrs_to_hard_f32": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_llrs_to_hard_f64": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_decode_ms_batch_f32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_decode_ms_batch_i8": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_decode_ms_batch_i16": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_hip_awgn_f32": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_uint64, _optp]),
+    "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
+                                         _c.c_uint64, _optp]),
+    "labrador_ldpc_hip_edge_crc": (_c.c_uint32, [_int]),
+    "labrador_ldpc_hip_device_count": (_int, []),
+    "labrador_ldpc_hip_last_error": (_c.c_char_p, []),
+    "labrador_ldpc_hip_version": (_c.c_char_p, []),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C labrador_ldpc_amd/csrc -j8`.  The HIP library is required (no CPU fallback).")
+    dll = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(dll, name)          # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    return dll
+
+
+lib = _load()
+
+
+def device_count() -> int:
+    return int(lib.labrador_ldpc_hip_device_count())
+
+
+def last_error() -> str:
+    return lib.labrador_ldpc_hip_last_error().decode()
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        raise LdpcHipError(f"status {status}: {last_error()}")
+
+
+_NP_SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.int8): "i8", np.dtype(np.int16): "i16",
+              np.dtype(np.float64): "f64"}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(a) -> int:
+    return a.data_ptr() if _is_torch(a) else a.ctypes.data
+
+
+def _suffix(a) -> str:
+    if _is_torch(a):
+        import torch
+        return {torch.float32: "f32", torch.int8: "i8", torch.int16: "i16", torch.float64: "f64"}[a.dtype]
+    return _NP_SUFFIX[a.dtype]
+
+
+# (submatrix_size, circulant_size) per code: src/codes/mod.rs:109-241
+_SUBMATRIX = {0: (16, 16), 1: (32, 32), 2: (64, 64), 3: (128, 32), 4: (256, 64), 5: (512, 128),
+              6: (512, 128), 7: (1024, 256), 8: (2048, 512)}
+
+
+class LDPCCode(enum.IntEnum):
+    """`enum LDPCCode` (src/codes/mod.rs:37-66) with the crate's method names."""
+
+    TC128 = 0
+    TC256 = 1
+    TC512 = 2
+    TM1280 = 3
+    TM1536 = 4
+    TM2048 = 5
+    TM5120 = 6
+    TM6144 = 7
+    TM8192 = 8
+
+    # ---- parameters: src/codes/mod.rs:381-409 ----
+    def n(self) -> int:
+        return int(lib.labrador_ldpc_code_n(int(self)))
+
+    def k(self) -> int:
+        return int(lib.labrador_ldpc_code_k(int(self)))
+
+    def punctured_bits(self) -> int:
+        return self.output_len() * 8 - self.n()
+
+    def submatrix_size(self) -> int:
+        return _SUBMATRIX[int(self)][0]
+
+    def circulant_size(self) -> int:
+        return _SUBMATRIX[int(self)][1]
+
+    def paritycheck_sum(self) -> int:
+        return (self.decode_ms_working_len() - 3 * self.n() - 3 * self.punctured_bits() + 2 * self.k()) // 2
+
+    # ---- sizes: src/decoder.rs:93-116 ----
+    def decode_bf_working_len(self) -> int:
+        return int(lib.labrador_ldpc_bf_working_len(int(self)))
+
+    def decode_ms_working_len(self) -> int:
+        return int(lib.labrador_ldpc_ms_working_len(int(self)))
+
+    def decode_ms_working_u8_len(self) -> int:
+        return int(lib.labrador_ldpc_ms_working_u8_len(int(self)))
+
+    def output_len(self) -> int:
+        return int(lib.labrador_ldpc_output_len(int(self)))
+
+    # ---- encoder: src/encoder.rs:293-315 ----
+    def encode(self, codeword: np.ndarray) -> np.ndarray:
+        """Set the parity bytes of `codeword` (n/8 bytes, first k/8 = data) in place."""
+        cw = _as_u8(codeword, self.n() // 8, "codeword must be n bits long")
+        lib.labrador_ldpc_encode(int(self), cw.ctypes.data)
+        return cw
+
+    def copy_encode(self, data: np.ndarray, codeword: np.ndarray) -> np.ndarray:
+        d = _as_u8(data, self.k() // 8, "data must be k bits long")
+        cw = _as_u8(codeword, self.n() // 8, "codeword must be n bits long")
+        lib.labrador_ldpc_copy_encode(int(self), d.ctypes.data, cw.ctypes.data)
+        return cw
+
+    # ---- LLR helpers: src/decoder.rs:484-509 ----
+    def hard_to_llrs(self, input: np.ndarray, llrs: np.ndarray) -> None:
+        inp = _as_u8(input, self.n() // 8, "input.len() != n/8")
+        if llrs.shape != (self.n(),):
+            raise ValueError("llrs.len() != n")
+        getattr(lib, "labrador_ldpc_hard_to_llrs_" + _suffix(llrs))(int(self), inp.ctypes.data, llrs.ctypes.data)
+
+    def llrs_to_hard(self, llrs: np.ndarray, output: np.ndarray) -> None:
+        if llrs.shape != (self.n(),):
+            raise ValueError("llrs.len() != n")
+        out = _as_u8(output, self.n() // 8, "output.len() != n/8")
+        getattr(lib, "labrador_ldpc_llrs_to_hard_" + _suffix(llrs))(int(self), llrs.ctypes.data, out.ctypes.data)
+
+    # ---- min-sum decoder: src/decoder.rs:347-475 ----
+    def decode_ms(self, llrs: np.ndarray, output: np.ndarray, working: Optional[np.ndarray] = None,
+                  working_u8: Optional[np.ndarray] = None, maxiters: int = 50) -> Tuple[bool, int]:
+        """One codeword on the GPU.  Returns (success, iterations) like the crate.
+
+        Length checks mirror the asserts of src/decoder.rs:356-359; `working`/`working_u8`
+        are optional here (the GPU keeps all message state on chip) but are length-checked
+        when given."""
+        if llrs.shape != (self.n(),):
+            raise ValueError("llrs.len() != n")
+        out = _as_u8(output, self.output_len(), "output.len() != (n+p)/8")
+        if working is not None and working.shape != (self.decode_ms_working_len(),):
+            raise ValueError("working.len() incorrect")
+        if working_u8 is not None and working_u8.shape != (self.decode_ms_working_u8_len(),):
+            raise ValueError("working_u8 != (n+p-k)/8")
+        llrs = np.ascontiguousarray(llrs)
+        iters = ctypes.c_size_t(0)
+        fn = getattr(lib, "labrador_ldpc_decode_ms_" + _suffix(llrs))
+        ok = fn(int(self), llrs.ctypes.data, out.ctypes.data,
+                working.ctypes.data if working is not None else None,
+                working_u8.ctypes.data if working_u8 is not None else None,
+                maxiters, ctypes.byref(iters))
+        err = last_error()
+        if not ok and err:
+            raise LdpcHipError(err)
+        return bool(ok), int(iters.value)
+
+    def decode_ms_batch(self, llrs, maxiters: int = 50, output=None, iters=None, success=None,
+                        variant: int = 0, stream: Optional[int] = None):
+        """Decode `llrs[batch, n]`.
+
+        numpy arrays are host buffers (the call stages them and returns when results are
+        back); torch CUDA tensors are device-resident buffers: the call only enqueues the
+        kernel on the tensor's device, on `stream` (default: torch's current stream).
+        Returns (output[batch, output_len] u8, iters[batch] u32/i32, success[batch] u8)."""
+        if llrs.ndim != 2 or llrs.shape[1] != self.n():
+            raise ValueError("llrs must be [batch, n]")
+        batch = llrs.shape[0]
+        fn = getattr(lib, "labrador_ldpc_decode_ms_batch_" + _suffix(llrs), None)
+        if fn is None:
+            raise LdpcHipError(f"no batched kernel for dtype {llrs.dtype}")
+        if _is_torch(llrs):
+            import torch
+            if not llrs.is_cuda:
+                raise ValueError("torch tensors must live on the GPU (use numpy for host buffers)")
+            if not llrs.is_contiguous():
+                raise ValueError("llrs must be contiguous")
+            dev = llrs.device
+            if output is None:
+                output = torch.empty((batch, self.output_len()), dtype=torch.uint8, device=dev)
+            if iters is None:
+                iters = torch.empty((batch,), dtype=torch.int32, device=dev)
+            if success is None:
+                success = torch.empty((batch,), dtype=torch.uint8, device=dev)
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, variant)
+        else:
+            llrs = np.ascontiguousarray(llrs)
+            if output is None:
+                output = np.empty((batch, self.output_len()), dtype=np.uint8)
+            if iters is None:
+                iters = np.empty((batch,), dtype=np.uint32)
+            if success is None:
+                success = np.empty((batch,), dtype=np.uint8)
+            opts = HipOpts(-1, MEM_HOST, stream, variant)
+        _check(fn(int(self), _ptr(llrs), _ptr(output), _ptr(iters), _ptr(success), batch, maxiters,
+                  ctypes.byref(opts)))
+        return output, iters, success
+
+    # ---- synthetic channel (harness) ----
+    def awgn_frames(self, codewords, batch: int, sigma: float, seed: int, dtype="f32",
+                    scale: float = 8.0, lim: int = 31, out=None, stream: Optional[int] = None):
+        """Fill `out[batch, n]` (device tensor) with BPSK+AWGN LLRs of the device-resident
+        codeword pool `codewords[pool, n/8]` (see labrador_ldpc_hip_awgn_*)."""
+        import torch
+        if not (codewords.is_cuda and codewords.dtype == torch.uint8 and codewords.is_contiguous()):
+            raise ValueError("codewords must be a contiguous uint8 CUDA tensor [pool, n/8]")
+        dev = codewords.device
+        tdt = {"f32": torch.float32, "i8": torch.int8}[dtype]
+        if out is None:
+            out = torch.empty((batch, self.n()), dtype=tdt, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0)
+        if dtype == "f32":
+            _check(lib.labrador_ldpc_hip_awgn_f32(int(self), codewords.data_ptr(), codewords.shape[0],
+                                                  out.data_ptr(), batch, sigma, seed, ctypes.byref(opts)))
+        else:
+            _check(lib.labrador_ldpc_hip_awgn_i8(int(self), codewords.data_ptr(), codewords.shape[0],
+                                                 out.data_ptr(), batch, sigma, scale, lim, seed,
+                                                 ctypes.byref(opts)))
+        return out
+
+
+def _as_u8(a: np.ndarray, length: int, msg: str) -> np.ndarray:
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 1 or not a.flags.c_contiguous:
+        raise ValueError("expected a contiguous 1-D uint8 numpy array")
+    if a.shape[0] != length:
+        raise ValueError(msg)
+    return a

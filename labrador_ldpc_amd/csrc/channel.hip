@@ -1,0 +1,111 @@
+// channel.hip -- synthetic BPSK + AWGN frames, generated on the device.
+//
+// Harness side of the path: what perftest's ms_trial does per frame on the CPU
+// (/root/reference/perftest/src/main.rs:10-18: encode, hard_to_llrs -> +-1, add Normal noise)
+// done for a whole batch in HBM, so that the 16 GiB/GPU of LLRs of the TM8192 configuration
+// never cross PCIe.  One thread makes four consecutive samples: one Philox4x32-10 block
+// keyed by the seed and counted by (sample/4, frame), two Box-Muller pairs, one 16-byte
+// (f32) or 4-byte (i8) store -- fully coalesced, HBM-write bound.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "channel.hpp"
+
+namespace ldpc {
+
+namespace {
+
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = U4{hi1 ^ ctr.y ^ k0, lo1, hi0 ^ ctr.w ^ k1, lo0};
+        k0 += W0;
+        k1 += W1;
+    }
+    return ctr;
+}
+
+// two standard normals from two 32-bit words (Box-Muller; u1 in (0,1], u2 in [0,1))
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
+{
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+template <class T> struct Quant;
+template <> struct Quant<float> {
+    static __device__ __forceinline__ float q(float y, float, int) { return y; }
+};
+template <> struct Quant<int8_t> {
+    static __device__ __forceinline__ int8_t q(float y, float scale, int lim)
+    {
+        int v = (int)rintf(scale * y);
+        v = v < -lim ? -lim : (v > lim ? lim : v);
+        return (int8_t)v;
+    }
+};
+
+template <class T>
+__global__ void __launch_bounds__(256)
+awgn_kernel(const uint8_t *__restrict__ codewords, uint32_t pool, T *__restrict__ llrs,
+            uint32_t n, uint64_t total_quads, float sigma, float scale, int lim,
+            uint32_t seed_lo, uint32_t seed_hi)
+{
+    const uint32_t quads_per_frame = n / 4;
+    for (uint64_t qd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < total_quads;
+         qd += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t frame = qd / quads_per_frame;
+        const uint32_t q = (uint32_t)(qd - frame * quads_per_frame);
+        const U4 rnd = philox4x32_10(U4{q, (uint32_t)frame, (uint32_t)(frame >> 32), 0u}, seed_lo, seed_hi);
+        float z[4];
+        box_muller(rnd.x, rnd.y, z[0], z[1]);
+        box_muller(rnd.z, rnd.w, z[2], z[3]);
+        const uint32_t cwi = (uint32_t)(frame % pool);
+        const uint32_t byte = codewords[(size_t)cwi * (n / 8) + q / 2];
+        const uint32_t nib = (q & 1) ? (byte & 0xF) : (byte >> 4);      // MSB-first bits 4q..4q+3
+        T o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = ((nib >> (3 - j)) & 1) ? -1.0f : 1.0f;      // bit 1 -> -1 (decoder.rs:487-490)
+            o[j] = Quant<T>::q(s + sigma * z[j], scale, lim);
+        }
+        T *dst = llrs + qd * 4;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4 *>(dst) = float4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        } else {
+            *reinterpret_cast<char4 *>(dst) = char4{(char)o[0], (char)o[1], (char)o[2], (char)o[3]};
+        }
+    }
+}
+
+}  // namespace
+
+template <class T>
+hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, size_t batch, float sigma,
+                       float scale, int lim, uint64_t seed, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    const uint64_t total_quads = (uint64_t)batch * (n / 4);
+    uint64_t blocks = (total_quads + 255) / 256;
+    if (blocks > 256ull * 32) blocks = 256ull * 32;
+    hipLaunchKernelGGL((awgn_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, codewords,
+                       (uint32_t)pool, llrs, (uint32_t)n, total_quads, sigma, scale, lim,
+                       (uint32_t)seed, (uint32_t)(seed >> 32));
+    return hipGetLastError();
+}
+
+template hipError_t launch_awgn<float>(const uint8_t *, size_t, float *, int, size_t, float, float, int, uint64_t, hipStream_t);
+template hipError_t launch_awgn<int8_t>(const uint8_t *, size_t, int8_t *, int, size_t, float, float, int, uint64_t, hipStream_t);
+
+}  // namespace ldpc

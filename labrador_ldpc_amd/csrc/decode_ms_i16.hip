@@ -1,0 +1,26 @@
+// decode_ms_i16.hip -- i16 instantiations of the min-sum kernel (decode_ms::<i16>,
+// /root/reference/src/decoder.rs:51-59, :347-475; C entry capi/src/lib.rs:105-111).
+#include "decode_ms_launch.hpp"
+
+namespace ldpc {
+
+template <>
+hipError_t launch_decode_ms<int16_t>(int code, int variant, const int16_t *llrs, uint8_t *output,
+                                    uint32_t *iters, uint8_t *success, size_t batch,
+                                    uint32_t maxiters, hipStream_t stream)
+{
+    switch (code) {
+        LDPC_CASE(TC128,  int16_t, 1)
+        LDPC_CASE(TC256,  int16_t, 1)
+        LDPC_CASE(TC512,  int16_t, 1)
+        LDPC_CASE(TM1280, int16_t, 1)
+        LDPC_CASE(TM1536, int16_t, 2)
+        LDPC_CASE(TM2048, int16_t, 4)
+        LDPC_CASE(TM5120, int16_t, 1)
+        LDPC_CASE(TM6144, int16_t, 2)
+        LDPC_CASE(TM8192, int16_t, 4)
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ldpc
