@@ -76,11 +76,43 @@ SYMBOLS = {
 }
 
 
+def _preload_hip_runtime() -> str:
+    """liblabrador_ldpc_hip.so is linked without the HIP runtime; supply ONE for the process.
+
+    If torch is installed, its bundled libamdhip64.so is used (found without importing torch), so
+    that this library and torch share one runtime -- device pointers, streams and events are then
+    interchangeable, whichever is imported first.  Otherwise the system ROCm runtime is used."""
+    import importlib.util
+    cands = []
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cands.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            return c
+        except OSError as e:      # try the next candidate
+            errs.append(f"{c}: {e}")
+    raise ImportError("no HIP runtime (libamdhip64.so) could be loaded: " + "; ".join(errs))
+
+
 def _load() -> ctypes.CDLL:
+    global LIB_PATH
+    LIB_PATH = os.environ.get("LABRADOR_LDPC_HIP_LIB", LIB_PATH)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C labrador_ldpc_amd/csrc -j8`.  The HIP library is required (no CPU fallback).")
+    global HIP_RUNTIME
+    HIP_RUNTIME = _preload_hip_runtime()
     dll = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(dll, name)          # AttributeError if the .so does not export it
@@ -88,6 +120,7 @@ def _load() -> ctypes.CDLL:
     return dll
 
 
+HIP_RUNTIME = ""
 lib = _load()
 
 

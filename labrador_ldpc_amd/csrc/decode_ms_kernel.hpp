@@ -14,21 +14,23 @@
 //    run along i and every block is a rotation (inside quarters, for pi_k) each LDS access
 //    of a wave is unit-stride with at most one wrap: conflict-free, no index tables.
 //
-//  * COMPRESSED CHECK STATE.  The reference keeps u[E] and v[E] (decoder.rs:375-376).
-//    Here a check keeps {min1, min2, sign} and each edge keeps v; u is re-derived from
-//    them exactly as decoder.rs:391-405 does.  Everything lives in VGPRs for the whole
-//    decode; the LLRs are read from HBM once, hard bits written once.
+//  * MESSAGE STATE IN REGISTERS.  The reference keeps u[E], v[E], min1[C], min2[C] and a
+//    sign bitmap in memory (decoder.rs:375-378) and derives u from them at the start of the
+//    next iteration (decoder.rs:391-405).  Here the check side derives the next u at the END
+//    of its update, as "smallest |v| among the OTHER edges of the check" with the product of
+//    the other edges' signs -- the same value decoder.rs:391-405 selects through min1/min2
+//    (proof in DESIGN.md) -- so per edge only u and v are kept, in VGPRs, for the whole
+//    decode.  LLRs are read from HBM once, hard bits written once.
 //
 //  * ORDER.  Marginals are accumulated per variable in the reference's edge order
 //    restricted to that variable (LLR first, then blocks by (block row, term)), with the
 //    same single IEEE / saturating operations (decoder.rs:408), so floating-point and
-//    saturating-integer results agree bit for bit.  Min/second-min, sign and parity
-//    accumulation are order-independent (decoder.rs:430-447).
+//    saturating-integer results agree bit for bit.  Min, sign and parity accumulation are
+//    order-independent (decoder.rs:430-447).
 //
-// One iteration = phase A1 (check side: u for the exchanged edges -> LDS) | barrier |
-// phase A2 (variable side: marginals, decoder.rs:382-411) | barrier | phase B (check side:
-// new v with self-correction, mins, signs, parity, decoder.rs:419-450).  The "all parities
-// satisfied" vote (decoder.rs:453) is an LDS flag read after the next barrier.
+// One iteration = variable phase (marginals, decoder.rs:382-411) | barrier | check phase
+// (new v with self-correction, next u, parity; decoder.rs:419-450) | barrier.  The "all
+// parities satisfied" vote (decoder.rs:453) is an LDS flag read after the barrier.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -37,12 +39,15 @@
 
 #include "codes.hpp"
 
+#define LDPC_INLINE __attribute__((always_inline))
+#define LDPC_DEV __device__ __forceinline__
+
 namespace ldpc {
 
 // ---- compile-time loop ------------------------------------------------------------------
 template <int N> struct IC { static constexpr int value = N; constexpr operator int() const { return N; } };
 template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F &&f)
+LDPC_DEV void static_for(F &&f)
 {
     if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
 }
@@ -83,54 +88,112 @@ constexpr int col_slot(const Prototype &p, int col)
     for (int i = 0; i < col; ++i) c += col_exchanged(p, i) ? 1 : 0;
     return c;
 }
+constexpr int row_degree(const Prototype &p, int row)
+{
+    int c = 0;
+    for (int b = 0; b < p.n_blocks; ++b) c += p.blk[b].row == row ? 1 : 0;
+    return c;
+}
+// block index of the j-th block of block row `row`
+constexpr int row_block(const Prototype &p, int row, int j)
+{
+    for (int b = 0; b < p.n_blocks; ++b)
+        if (p.blk[b].row == row && j-- == 0) return b;
+    return -1;
+}
 
 // ---- arithmetic per LLR type: DecodeFrom, decoder.rs:22-86 ----------------------------------
+// Register values are kept so that "negative" (hard_bit, decoder.rs:49/:76) is exactly bit 31
+// of the 32-bit pattern: true for two's-complement ints, and true for floats because no
+// value in this kernel is ever -0.0 (LLRs are canonicalised with +0.0 on load; sums and
+// differences of such values cannot produce -0.0; see DESIGN.md "signed zeros").
 template <class T> struct Ops;
 
 template <> struct Ops<float> {                       // decoder.rs:69-77
-    using R = float;                                   // register type
-    static __device__ __forceinline__ R zero() { return 0.0f; }
-    static __device__ __forceinline__ R maxval() { return FLT_MAX; }
-    static __device__ __forceinline__ R load(float x) { return x; }
-    static __device__ __forceinline__ float store(R x) { return x; }
-    static __device__ __forceinline__ R abs(R x) { return __builtin_fabsf(x); }   // sign-bit mask, :73
-    static __device__ __forceinline__ R add(R a, R b) { return a + b; }           // :74
-    static __device__ __forceinline__ R sub(R a, R b) { return a - b; }           // :75
-    static __device__ __forceinline__ R negate(R x) { return -x; }
-    static __device__ __forceinline__ bool neg(R x) { return x < 0.0f; }          // hard_bit, :76
-    static __device__ __forceinline__ bool is_zero(R x) { return x == 0.0f; }
-    static __device__ __forceinline__ bool eq(R a, R b) { return a == b; }
-    // two smallest of {m1, m2, a}: equals the strict-< update of decoder.rs:430-435
-    static __device__ __forceinline__ void min2(R a, R &m1, R &m2)
+    using R = float;
+    LDPC_DEV static R zero() { return 0.0f; }
+    LDPC_DEV static R maxval() { return FLT_MAX; }                              // :72
+    LDPC_DEV static R load(float x) { return x + 0.0f; }                        // -0.0 -> +0.0
+    LDPC_DEV static float store(R x) { return x; }
+    LDPC_DEV static R from_lds(float x) { return x; }                           // already canonical
+    LDPC_DEV static int bits(R x) { return __float_as_int(x); }
+    LDPC_DEV static R add(R a, R b) { return a + b; }                           // :74
+    LDPC_DEV static R sub(R a, R b) { return a - b; }                           // :75
+    LDPC_DEV static R mag(R x) { return __builtin_fabsf(x); }                   // :73 (may be +inf)
+    LDPC_DEV static R min2(R a, R b) { return __builtin_fminf(a, b); }
+    LDPC_DEV static R min3(R a, R b, R c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+    // magnitude `m` (>= 0) with the sign taken from bit 31 of `s`
+    LDPC_DEV static R with_sign(R m, int s)
     {
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
-        m1 = __builtin_fminf(m1, a);
+        return __int_as_float((__float_as_int(m) & 0x7FFFFFFF) | (s & (int)0x80000000));
     }
+    LDPC_DEV static R select_zero(bool z, R x) { return z ? 0.0f : x; }
 };
 
 template <class I, int LO, int HI> struct IntOps {     // decoder.rs:42-59
     using R = int;
-    static __device__ __forceinline__ R zero() { return 0; }
-    static __device__ __forceinline__ R maxval() { return HI; }
-    static __device__ __forceinline__ R load(I x) { return (int)x; }
-    static __device__ __forceinline__ I store(R x) { return (I)x; }
-    static __device__ __forceinline__ R clamp(R x) { return x < LO ? LO : (x > HI ? HI : x); }
-    static __device__ __forceinline__ R abs(R x) { R a = x < 0 ? -x : x; return a > HI ? HI : a; } // saturating_abs
-    static __device__ __forceinline__ R add(R a, R b) { return clamp(a + b); }    // saturating_add
-    static __device__ __forceinline__ R sub(R a, R b) { return clamp(a - b); }    // saturating_sub
-    static __device__ __forceinline__ R negate(R x) { return -x; }
-    static __device__ __forceinline__ bool neg(R x) { return x < 0; }
-    static __device__ __forceinline__ bool is_zero(R x) { return x == 0; }
-    static __device__ __forceinline__ bool eq(R a, R b) { return a == b; }
-    static __device__ __forceinline__ void min2(R a, R &m1, R &m2)
-    {
-        const R lo = a < m1 ? a : m1, hi = a < m1 ? m1 : a;   // min/max(a, m1)
-        m2 = hi < m2 ? hi : m2;
-        m1 = lo;
-    }
+    LDPC_DEV static R zero() { return 0; }
+    LDPC_DEV static R maxval() { return HI; }
+    LDPC_DEV static R load(I x) { return (int)x; }
+    LDPC_DEV static I store(R x) { return (I)x; }
+    LDPC_DEV static R from_lds(I x) { return (int)x; }
+    LDPC_DEV static int bits(R x) { return x; }
+    LDPC_DEV static R clamp(R x) { return x < LO ? LO : (x > HI ? HI : x); }
+    LDPC_DEV static R add(R a, R b) { return clamp(a + b); }                    // saturating_add
+    LDPC_DEV static R sub(R a, R b) { return clamp(a - b); }                    // saturating_sub
+    LDPC_DEV static R mag(R x) { R a = x < 0 ? -x : x; return a > HI ? HI : a; } // saturating_abs
+    LDPC_DEV static R min2(R a, R b) { return a < b ? a : b; }
+    LDPC_DEV static R min3(R a, R b, R c) { return min2(min2(a, b), c); }
+    LDPC_DEV static R with_sign(R m, int s) { return s < 0 ? -m : m; }
+    LDPC_DEV static R select_zero(bool z, R x) { return z ? 0 : x; }
 };
 template <> struct Ops<int8_t>  : IntOps<int8_t, -128, 127> {};
 template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
+
+// e[i] = min(maxval, min over j != i of a[j]).  Equals what decoder.rs:391-395 selects from
+// (min1, min2): min2 if |v_i| is a smallest magnitude of the check, min1 otherwise -- and
+// min1/min2 start at maxval (decoder.rs:414-415) and are only replaced by strictly smaller
+// values (:430-434), hence the clamp.  Elements are grouped in threes so that one min3 per
+// element finishes the job: ~1.7 operations per edge at degree 6, ~1.9 at degree 18.
+template <class O, int D>
+LDPC_DEV void exclusive_min(const typename O::R (&a)[D], typename O::R (&e)[D])
+{
+    using R = typename O::R;
+    const R MX = O::maxval();
+    if constexpr (D == 1) {
+        e[0] = MX;
+    } else if constexpr (D == 2) {
+        e[0] = O::min2(a[1], MX);
+        e[1] = O::min2(a[0], MX);
+    } else if constexpr (D == 3) {
+        e[0] = O::min3(a[1], a[2], MX);
+        e[1] = O::min3(a[0], a[2], MX);
+        e[2] = O::min3(a[0], a[1], MX);
+    } else {
+        constexpr int G = (D + 2) / 3;
+        R t[G], x[G];
+        static_for<0, G>([&](auto g_) LDPC_INLINE {
+            constexpr int g = decltype(g_)::value, n = (3 * g + 3 <= D) ? 3 : D - 3 * g;
+            if constexpr (n == 3) t[g] = O::min3(a[3 * g], a[3 * g + 1], a[3 * g + 2]);
+            else if constexpr (n == 2) t[g] = O::min2(a[3 * g], a[3 * g + 1]);
+            else t[g] = a[3 * g];
+        });
+        exclusive_min<O, G>(t, x);
+        static_for<0, G>([&](auto g_) LDPC_INLINE {
+            constexpr int g = decltype(g_)::value, n = (3 * g + 3 <= D) ? 3 : D - 3 * g;
+            if constexpr (n == 3) {
+                e[3 * g]     = O::min3(a[3 * g + 1], a[3 * g + 2], x[g]);
+                e[3 * g + 1] = O::min3(a[3 * g],     a[3 * g + 2], x[g]);
+                e[3 * g + 2] = O::min3(a[3 * g],     a[3 * g + 1], x[g]);
+            } else if constexpr (n == 2) {
+                e[3 * g]     = O::min2(a[3 * g + 1], x[g]);
+                e[3 * g + 1] = O::min2(a[3 * g],     x[g]);
+            } else {
+                e[3 * g] = x[g];
+            }
+        });
+    }
+}
 
 // ---- kernel geometry -----------------------------------------------------------------------
 template <int CODE, class T, int IPT>
@@ -150,14 +213,15 @@ struct Geometry {
     static_assert(M % IPT == 0 && NT >= 8 && (NT & (NT - 1)) == 0, "bad IPT");
 };
 
-// pi_k(i) for a run-time i; collapses to literals when the quarter index is known at compile time
+// pi_k(i) for check index i whose quarter j = i / (M/4) the caller supplies: a literal when a
+// thread's indices never leave a quarter, a wave-uniform scalar when waves do not straddle
+// quarters (then the selects below are scalar), a per-lane value otherwise.
 template <int K, int M>
-__device__ __forceinline__ int pi_dev(int i)
+LDPC_DEV int pi_dev(int i, int j)
 {
     constexpr int LQ = ilog2(M / 4), Q = M / 4;
     constexpr int P0 = phi_of(K, 0, M), P1 = phi_of(K, 1, M), P2 = phi_of(K, 2, M), P3 = phi_of(K, 3, M);
     constexpr int TH = theta_of(K);
-    const int j = i >> LQ;
     const int phi = j == 0 ? P0 : (j == 1 ? P1 : (j == 2 ? P2 : P3));
     return (((TH + j) & 3) << LQ) + ((phi + i) & (Q - 1));
 }
@@ -176,9 +240,14 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                   NCOLS = GEO::NCOLS, NTX = GEO::NTX, NX = GEO::NX, NXC = GEO::NXC;
     constexpr int N = CODES[CODE].n;
 
-    __shared__ T xu[G][NX * M];       // check -> variable messages of the exchanged blocks
-    __shared__ T xva[G][NXC * M];     // marginals of the block columns those blocks touch
-    __shared__ int unsat[G][2];       // "some parity check failed" per codeword, double-buffered
+    // LDS, per codeword of the workgroup: [ xu: NX blocks | xva: NXC block columns | 2 flags ]
+    //   xu   check -> variable messages of the exchanged blocks, stored at the VARIABLE's index
+    //   xva  marginals of the block columns those blocks touch
+    //   flag "some parity check failed", double-buffered over iterations
+    constexpr int SZ = sizeof(T);
+    constexpr int XVA_OFF = NX * M * SZ, FLAG_OFF = (NX + NXC) * M * SZ;
+    constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) char lds[G * GROUP_BYTES];
 
     const int tid = threadIdx.x;
     const int grp = G == 1 ? 0 : tid / NT;
@@ -186,133 +255,203 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     __builtin_assume(t >= 0 && t < NT);
     const uint32_t cw = blockIdx.x * G + grp;
     const bool live = cw < batch;
-
-    // variable index (inside its block column) that check i of block B is wired to
-    auto wire = [&](auto B, int i) -> int {
-        constexpr Block blk = P.blk[B];
-        if constexpr (blk.kind == BLK_I) return (i + blk.val) & (M - 1);
-        else return pi_dev<blk.val, M>(i);
+    char *const gbase = lds + (G == 1 ? 0 : grp * GROUP_BYTES);
+    auto lds_at = [&](int byte_off) LDPC_INLINE -> T & { return *reinterpret_cast<T *>(gbase + byte_off); };
+    auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
+        return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
 
-    // ---- state, all in registers -----------------------------------------------------------
-    R v[IPT][NB];                 // variable -> check message per edge        (decoder.rs:376)
-    R m1[IPT][NROWS], m2[IPT][NROWS];   // two smallest |v| per check           (decoder.rs:378)
-    bool sg[IPT][NROWS];          // product of signs per check                 (decoder.rs:367)
-    R va[IPT][NCOLS];             // marginals                                  (decoder.rs:377)
-    R llr[IPT][NTX];              // channel LLRs, read from HBM once
-
-    static_for<0, IPT>([&](auto S) {
-        static_for<0, NB>([&](auto B) { v[S][B] = O::zero(); });               // decoder.rs:374
-        static_for<0, NROWS>([&](auto Rw) { m1[S][Rw] = O::zero(); m2[S][Rw] = O::zero(); sg[S][Rw] = false; });
-        static_for<0, NCOLS>([&](auto C) { va[S][C] = O::zero(); });
-        static_for<0, NTX>([&](auto C) {
-            const int i = S * NT + t;
-            llr[S][C] = live ? O::load(llrs[(size_t)cw * N + C * M + i]) : O::zero();
-        });
-    });
-    if (t < 2) unsat[grp][t] = 0;
-    __syncthreads();
-
-    auto emit = [&](uint32_t iters, bool ok) {
-        // hard decision of the marginals, MSB first (decoder.rs:455-461 / :467-473)
-        static_for<0, IPT>([&](auto S) {
-            static_for<0, NCOLS>([&](auto C) {
-                const unsigned long long bits = __ballot(O::neg(va[S][C]));
-                const int i = S * NT + t;
-                if constexpr (NT >= 64) {
-                    if ((tid & 63) == 0 && live) {
-                        const unsigned long long w = __builtin_bswap64(__builtin_bitreverse64(bits));
-                        *reinterpret_cast<unsigned long long *>(output + (size_t)cw * GEO::OUT_LEN + (C * M + i) / 8) = w;
-                    }
-                } else {
-                    if ((tid & 7) == 0 && live) {
-                        const unsigned b8 = (unsigned)(bits >> (tid & 63)) & 0xFFu;
-                        output[(size_t)cw * GEO::OUT_LEN + (C * M + i) / 8] = (uint8_t)(__builtin_bitreverse32(b8) >> 24);
-                    }
+    // Byte offset, inside one block's M*SZ-byte LDS region, of the variable that check
+    // i = S*NT + t of block B is wired to; `tb` is t*SZ.  Identity blocks rotate the whole
+    // region, pi_k blocks move quarter j to quarter (theta_k + j) mod 4 and rotate inside it
+    // (compact_parity_checks.rs:107-108).  Two VALU operations: add, and-or.
+    constexpr int Q = M / 4, LQ = ilog2(Q);
+    constexpr bool QUARTER_LITERAL = NT <= Q;            // a thread's index S never leaves a quarter
+    constexpr bool QUARTER_SCALAR = !QUARTER_LITERAL && Q >= 64;   // a wave never straddles quarters
+    int rot_s[IPT][NB], base_s[IPT][NB];                 // wave-uniform (SGPR) constants, QUARTER_SCALAR only
+    if constexpr (QUARTER_SCALAR) {
+        const int jw = __builtin_amdgcn_readfirstlane(t >> LQ);
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                constexpr Block blk = P.blk[B];
+                if constexpr (blk.kind == BLK_P) {
+                    constexpr int K = blk.val;
+                    const int j = S * (NT / Q) + jw;
+                    const int phi = j == 0 ? phi_of(K, 0, M) : (j == 1 ? phi_of(K, 1, M) : (j == 2 ? phi_of(K, 2, M) : phi_of(K, 3, M)));
+                    rot_s[S][B] = (phi + S * NT) * SZ;
+                    base_s[S][B] = (((theta_of(K) + j) & 3) << LQ) * SZ;
                 }
             });
         });
-        if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
+    }
+    auto wire = [&](auto B_, auto S_, int tb) LDPC_INLINE -> int {
+        constexpr int B = decltype(B_)::value, S = decltype(S_)::value;
+        constexpr Block blk = P.blk[B];
+        if constexpr (blk.kind == BLK_I) {
+            return (tb + (S * NT + blk.val) * SZ) & (M * SZ - 1);
+        } else if constexpr (QUARTER_LITERAL) {
+            constexpr int j = (S * NT) / Q, K = blk.val;
+            return ((tb + (phi_of(K, j, M) + S * NT) * SZ) & (Q * SZ - 1)) | ((((theta_of(K) + j) & 3) << LQ) * SZ);
+        } else if constexpr (QUARTER_SCALAR) {
+            return ((tb + rot_s[S][B]) & (Q * SZ - 1)) | base_s[S][B];
+        } else {
+            return pi_dev<blk.val, M>(S * NT + tb / SZ, (S * NT + tb / SZ) >> LQ) * SZ;
+        }
     };
 
-    bool done = false;
-    for (uint32_t it = 0;; ++it) {
-        // ---- phase A1: check -> variable messages (decoder.rs:391-405) ------------------------
-        R u[IPT][NB];
-        static_for<0, IPT>([&](auto S) {
-            const int i = S * NT + t;
-            static_for<0, NB>([&](auto B) {
-                constexpr Block blk = P.blk[B];
-                constexpr int r = blk.row;
-                const R mag = O::eq(O::abs(v[S][B]), m1[S][r]) ? m2[S][r] : m1[S][r];   // :391-395
-                const bool flip = sg[S][r] != O::neg(v[S][B]);                           // :398-405
-                u[S][B] = flip ? O::negate(mag) : mag;
-                constexpr int slot = exch_slot(P, B);
-                if constexpr (slot >= 0) xu[grp][slot * M + wire(B, i)] = O::store(u[S][B]);
-            });
+    // ---- state, all in registers -----------------------------------------------------------
+    R u[IPT][NB];                 // check -> variable message per edge        (decoder.rs:375)
+    R v[IPT][NB];                 // variable -> check message per edge        (decoder.rs:376)
+    R va[IPT][NCOLS];             // marginals                                  (decoder.rs:377)
+    R llr[IPT][NTX];              // channel LLRs, read from HBM once
+
+    static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+        constexpr int S = decltype(S_)::value;
+        const int i = S * NT + t;
+        static_for<0, NB>([&](auto B_) LDPC_INLINE {
+            constexpr int B = decltype(B_)::value;
+            u[S][B] = O::zero();                                               // decoder.rs:374
+            v[S][B] = O::zero();
+            constexpr int slot = exch_slot(P, B);
+            if constexpr (slot >= 0) lds_at(slot * M * SZ + wire(B_, S_, t * SZ)) = O::store(O::zero());
         });
-        __syncthreads();
+        static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
+        static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+            constexpr int C = decltype(C_)::value;
+            llr[S][C] = live ? O::load(llrs[(size_t)cw * N + C * M + i]) : O::zero();
+        });
+    });
+    if (t < 2) flag_at(t) = 0;
 
-        // ---- verdict on the previous iteration (decoder.rs:453-463, :466-474) -----------------
-        if (!done) {
-            if (it > 0 && unsat[grp][(it - 1) & 1] == 0) { emit(it - 1, true); done = true; }
-            else if (it == maxiters) { emit(maxiters, false); done = true; }
-        }
-        if constexpr (G == 1) { if (done) break; }
-        else { if (__all(done)) break; }
-
-        // ---- phase A2: marginals (decoder.rs:382-383, :408) -----------------------------------
-        static_for<0, IPT>([&](auto S) {
+    // One iteration of message passing for this thread's indices: the two phases below.
+    auto variable_phase = [&]() LDPC_INLINE {
+        // marginals (decoder.rs:382-383, :408)
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value;
             const int i = S * NT + t;
-            static_for<0, NCOLS>([&](auto C) {
+            static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
+                constexpr int C = decltype(C_)::value;
                 R acc = O::zero();
                 if constexpr (C < NTX) acc = llr[S][C];
-                static_for<0, NB>([&](auto B) {
-                    constexpr Block blk = P.blk[B];
-                    if constexpr (blk.col == C) {
+                static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                    constexpr int B = decltype(B_)::value;
+                    if constexpr (P.blk[B].col == C) {
                         constexpr int slot = exch_slot(P, B);
-                        if constexpr (slot >= 0) acc = O::add(acc, O::load(xu[grp][slot * M + i]));
+                        if constexpr (slot >= 0) acc = O::add(acc, O::from_lds(lds_at(slot * M * SZ + i * SZ)));
                         else acc = O::add(acc, u[S][B]);
                     }
                 });
                 va[S][C] = acc;
                 constexpr int cs = col_slot(P, C);
-                if constexpr (cs >= 0) xva[grp][cs * M + i] = O::store(acc);
+                if constexpr (cs >= 0) lds_at(XVA_OFF + cs * M * SZ + i * SZ) = O::store(acc);
             });
         });
-        __syncthreads();
-        if (it > 0 && t == 0) unsat[grp][(it - 1) & 1] = 0;
+    };
 
-        // ---- phase B: variable -> check messages (decoder.rs:414-450) -------------------------
-        bool fail = false;
-        static_for<0, IPT>([&](auto S) {
-            const int i = S * NT + t;
-            static_for<0, NROWS>([&](auto Rw) {
-                R n1 = O::maxval(), n2 = O::maxval();                                    // :414-415
-                bool sgn = false, par = false;                                           // :416-417
-                static_for<0, NB>([&](auto B) {
+    auto check_phase = [&](uint32_t it) LDPC_INLINE {
+        // decoder.rs:414-450, and :391-405 of the NEXT iteration
+        int par_any = 0;          // bit 31 set if any owned check has odd parity
+        // LDS addresses of the exchanged edges are two VALU ops each from `tb`; making `tb`
+        // opaque per iteration stops the compiler from hoisting all of them into VGPRs that
+        // then stay live across the whole loop (which costs more in spills than it saves).
+        int tb = t * SZ;
+        asm volatile("" : "+v"(tb));
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value;
+            static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
+                constexpr int Rw = decltype(R_)::value;
+                constexpr int D = row_degree(P, Rw);
+                R a[D], e[D];
+                int sgn = 0, par = 0;
+                static_for<0, D>([&](auto J_) LDPC_INLINE {
+                    constexpr int J = decltype(J_)::value;
+                    constexpr int B = row_block(P, Rw, J);
                     constexpr Block blk = P.blk[B];
-                    if constexpr (blk.row == Rw) {
-                        constexpr int slot = exch_slot(P, B);
-                        R x;
-                        if constexpr (slot >= 0) x = O::load(xva[grp][col_slot(P, blk.col) * M + wire(B, i)]);
-                        else x = va[S][blk.col];
-                        const R nv = O::sub(x, u[S][B]);                                 // :421
-                        const R old = v[S][B];
-                        const bool keep = (O::neg(nv) == O::neg(old)) || O::is_zero(old); // :422
-                        const R nw = keep ? nv : O::zero();                              // :423-425
-                        v[S][B] = nw;
-                        O::min2(O::abs(nw), n1, n2);                                     // :430-435
-                        sgn ^= O::neg(nw);                                               // :439-441
-                        par ^= O::neg(x);                                                // :445-447
-                    }
+                    constexpr int slot = exch_slot(P, B);
+                    constexpr int cs = col_slot(P, blk.col);
+                    R x;
+                    if constexpr (slot >= 0) x = O::from_lds(lds_at(XVA_OFF + cs * M * SZ + wire(IC<B>{}, S_, tb)));
+                    else x = va[S][blk.col];
+                    const R nv = O::sub(x, u[S][B]);                                   // :421
+                    const R old = v[S][B];
+                    // keep nv if its sign equals old's or old is zero, else zero it (:422-425)
+                    const bool drop = ((O::bits(nv) ^ O::bits(old)) < 0) && (O::bits(old) != 0);
+                    const R nw = O::select_zero(drop, nv);
+                    v[S][B] = nw;
+                    a[J] = O::mag(nw);
+                    sgn ^= O::bits(nw);                                                // :439-441
+                    par ^= O::bits(x);                                                 // :445-447
                 });
-                m1[S][Rw] = n1; m2[S][Rw] = n2; sg[S][Rw] = sgn;
-                fail |= par;
+                exclusive_min<O, D>(a, e);                                             // :391-395, :430-435
+                static_for<0, D>([&](auto J_) LDPC_INLINE {
+                    constexpr int J = decltype(J_)::value;
+                    constexpr int B = row_block(P, Rw, J);
+                    const R un = O::with_sign(e[J], sgn ^ O::bits(v[S][B]));           // :398-405
+                    u[S][B] = un;
+                    constexpr int slot = exch_slot(P, B);
+                    if constexpr (slot >= 0) lds_at(slot * M * SZ + wire(IC<B>{}, S_, tb)) = O::store(un);
+                });
+                par_any |= par;
             });
         });
-        if (fail) unsat[grp][it & 1] = 1;
+        if (par_any < 0) flag_at(it) = 1;
+    };
+
+    // Codewords that share a wave (G > 1) finish at different iterations: a finished one
+    // simply stops updating (its lanes are masked off) until the whole wave is done.
+    bool done = false, ok = false;
+    uint32_t iters = maxiters;
+    for (uint32_t it = 0;; ++it) {
+        __syncthreads();          // u of the exchanged blocks and the parity vote are visible
+        // verdict on the previous iteration (decoder.rs:453-463, :466-474)
+        if (!done) {
+            if (it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
+            else if (it == maxiters) { done = true; }
+        }
+        if constexpr (G == 1) { if (done) break; }
+        else { if (__all(done)) break; }
+
+        if (G == 1 || !done) variable_phase();
+        __syncthreads();
+        if (it > 0 && t == 0) flag_at(it - 1) = 0;
+        if (G == 1 || !done) check_phase(it);
     }
+
+    // ---- hard decision of the marginals, MSB first (decoder.rs:455-461 / :467-473) ------------
+    if constexpr (NT >= 64) {
+        unsigned long long w[IPT][NCOLS];
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
+                const unsigned long long bits = __ballot(O::bits(va[S][C]) < 0);   // bit l = lane l
+                const unsigned lo = __builtin_bswap32(__builtin_bitreverse32((unsigned)bits));
+                const unsigned hi = __builtin_bswap32(__builtin_bitreverse32((unsigned)(bits >> 32)));
+                w[S][C] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            });
+        });
+        if ((tid & 63) == 0) {
+            uint8_t *dst = output + (size_t)cw * GEO::OUT_LEN + t / 8;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
+                    constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
+                    *reinterpret_cast<unsigned long long *>(dst + (C * M + S * NT) / 8) = w[S][C];
+                });
+            });
+        }
+    } else {
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
+                const unsigned long long bits = __ballot(O::bits(va[S][C]) < 0);
+                const unsigned b8 = (unsigned)(bits >> (tid & 56)) & 0xFFu;
+                if ((tid & 7) == 0 && live)
+                    output[(size_t)cw * GEO::OUT_LEN + (C * M + S * NT + t) / 8] = (uint8_t)(__builtin_bitreverse32(b8) >> 24);
+            });
+        });
+    }
+    if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
 }
+
 
 }  // namespace ldpc
