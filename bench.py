@@ -63,6 +63,7 @@ def main():
     import torch
     import torch.distributed as dist
     from labrador_ldpc_amd import LDPCCode
+    from labrador_ldpc_amd.sharding import frame_seed, reduce_max
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +90,7 @@ def main():
     for i in range(args.pool):
         code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
     d_pool = torch.from_numpy(pool).to(dev)
-    seed = (0x1DBC + int(code)) | (rank << 40)
+    seed = frame_seed(0x1DBC + int(code), rank)
     llrs = code.awgn_frames(d_pool, F, sigma, seed, dtype=args.dtype)
     out = torch.empty((F, code.output_len()), dtype=torch.uint8, device=dev)
     iters = torch.empty((F,), dtype=torch.int32, device=dev)
@@ -120,10 +121,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    stats = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max = float(stats[0]), float(stats[1])
+    elapsed, kernel_ms_max = reduce_max([elapsed, kernel_ms], device=dev)   # slowest rank
 
     mean_iters = float(iters.double().mean())
     frame_fail = 1.0 - float(succ.double().mean())

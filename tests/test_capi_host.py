@@ -1,0 +1,115 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header declares,
+its code tables reproduce the reference's known answers, host helpers behave like the crate's,
+and the decoders fail loudly (no CPU fallback) when there is no GPU.  No compute calls need a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import labrador_ldpc_amd as la
+from labrador_ldpc_amd import LDPCCode
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ["TC128", "TC256", "TC512", "TM1280", "TM1536", "TM2048", "TM5120", "TM6144", "TM8192"]
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "labrador_ldpc_hip.h")).read()
+    declared = set(re.findall(r"\b(labrador_ldpc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    dll = ctypes.CDLL(la.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(dll, name), f"{name} declared in the header but not exported"
+    assert declared == set(la.SYMBOLS), "python binding and header disagree"
+
+
+@pytest.mark.parametrize("code", list(LDPCCode), ids=NAMES)
+def test_tables_reproduce_reference_kats(code, kats):
+    """The constexpr tables the kernels are generated from: edge-order CRC (src/codes/mod.rs:521-523),
+    sizes (src/codes/mod.rs:109-241), encoder parity (src/encoder.rs:361-527)."""
+    s = kats["sizes"][code.name]
+    assert la.lib.labrador_ldpc_hip_edge_crc(int(code)) == kats["edge_crc"][int(code)]
+    assert (code.n(), code.k(), code.punctured_bits()) == (s["n"], s["k"], s["punctured_bits"])
+    assert code.submatrix_size() == s["submatrix_size"] and code.circulant_size() == s["circulant_size"]
+    assert code.paritycheck_sum() == s["paritycheck_sum"]
+    assert code.decode_bf_working_len() == s["decode_bf_working_len"]
+    assert code.decode_ms_working_len() == s["decode_ms_working_len"]
+    assert code.decode_ms_working_u8_len() == s["decode_ms_working_u8_len"]
+    assert code.output_len() == s["output_len"]
+    data = np.arange(code.k() // 8, dtype=np.uint8)
+    cw = np.zeros(code.n() // 8, dtype=np.uint8)
+    code.copy_encode(data, cw)
+    assert cw[code.k() // 8:].tolist() == kats["encode_parity"][code.name]
+    cw2 = np.zeros(code.n() // 8, dtype=np.uint8)
+    cw2[: code.k() // 8] = data
+    code.encode(cw2)
+    assert (cw2 == cw).all()
+
+
+def test_encoder_matches_oracle_on_random_data():
+    import oracle
+    rng = np.random.default_rng(1)
+    for code in LDPCCode:
+        data = rng.integers(0, 256, code.k() // 8, dtype=np.uint8)
+        cw = np.zeros(code.n() // 8, dtype=np.uint8)
+        code.copy_encode(data, cw)
+        assert (cw == oracle.copy_encode(code, data)).all()
+
+
+def test_hard_llr_helpers(kats):
+    h = kats["hard_llr"]
+    code = LDPCCode.TC128
+    hard = np.array(h["hard"], dtype=np.uint8)
+    for dt in (np.int8, np.int16, np.float32, np.float64):
+        llrs = np.zeros(code.n(), dtype=dt)
+        code.hard_to_llrs(hard, llrs)
+        assert llrs.tolist() == [dt(x) for x in h["llrs"]]
+        back = np.zeros(code.n() // 8, dtype=np.uint8)
+        code.llrs_to_hard(llrs, back)
+        assert back.tolist() == h["hard"]
+
+
+def test_out_of_range_code_is_rejected():
+    for bad in (-1, 9, 1000):
+        assert la.lib.labrador_ldpc_code_n(bad) == 0 and la.lib.labrador_ldpc_output_len(bad) == 0
+        assert la.lib.labrador_ldpc_hip_edge_crc(bad) == 0
+    out = np.zeros(4, dtype=np.uint8)
+    st = la.lib.labrador_ldpc_decode_ms_batch_f32(9, out.ctypes.data, out.ctypes.data, out.ctypes.data,
+                                                  out.ctypes.data, 1, 10, None)
+    assert st == -1 and "out of range" in la.last_error()
+
+
+def test_length_checks_mirror_the_crate_asserts():
+    code = LDPCCode.TC128
+    with pytest.raises(ValueError):
+        code.decode_ms(np.zeros(code.n() - 1, dtype=np.float32), np.zeros(code.output_len(), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        code.decode_ms(np.zeros(code.n(), dtype=np.float32), np.zeros(code.output_len() + 1, dtype=np.uint8))
+    with pytest.raises(ValueError):
+        code.decode_ms(np.zeros(code.n(), dtype=np.float32), np.zeros(code.output_len(), dtype=np.uint8),
+                       working=np.zeros(3, dtype=np.float32))
+    with pytest.raises(ValueError):
+        code.encode(np.zeros(code.n() // 8 + 1, dtype=np.uint8))
+
+
+def test_decode_without_gpu_fails_loudly():
+    """No CPU fallback: without a gfx950 device the batched call returns ENODEV and the
+    reference-shaped call raises."""
+    if la.device_count() > 0:
+        pytest.skip("a GPU is present")
+    code = LDPCCode.TC128
+    llrs = np.ones((2, code.n()), dtype=np.float32)
+    with pytest.raises(la.LdpcHipError) as e:
+        code.decode_ms_batch(llrs, 10)
+    assert "status -2" in str(e.value)
+    with pytest.raises(la.LdpcHipError):
+        code.decode_ms(llrs[0], np.zeros(code.output_len(), dtype=np.uint8))
+
+
+def test_unimplemented_entry_points_say_so():
+    code = LDPCCode.TC128
+    out = np.zeros(code.output_len(), dtype=np.uint8)
+    assert not la.lib.labrador_ldpc_decode_bf(0, out.ctypes.data, out.ctypes.data, out.ctypes.data, 10, None)
+    assert "not implemented" in la.last_error()
