@@ -1,0 +1,100 @@
+"""BASELINE.json's configurations at their FULL batch sizes, checked through size-independent
+properties (the oracle would need hours for these batches) plus an oracle comparison on a sample:
+
+  * status consistency: success => iters < max_iters, failure => iters == max_iters;
+  * every successful output is a codeword: re-decoding its own hard decision (as +-1 LLRs) succeeds
+    immediately (iteration 0 for TC, <= 1 for the punctured TM codes) and returns the same bits --
+    decode is idempotent on its successes, which also exercises the punctured-bit reconstruction;
+  * determinism: a second launch gives byte-identical results;
+  * batch-split invariance: decoding a slice alone equals the slice of the full decode;
+  * the frame-error rate is in the regime the oracle sample shows.
+Frames are generated on the device (labrador_ldpc_hip_awgn_*), so nothing large crosses PCIe."""
+import numpy as np
+import pytest
+
+import oracle
+from labrador_ldpc_amd import LDPCCode
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+# (code, dtype, frames, Eb/N0 dB): BASELINE.json configs 2-5 (per-GPU share for the 8-GPU ones)
+CONFIGS = [
+    pytest.param(LDPCCode.TC512, "f32", 65536, 2.0, id="config2-TC512-f32-65536"),
+    pytest.param(LDPCCode.TM2048, "f32", 1048576, 2.0, id="config3-TM2048-f32-1048576"),
+    pytest.param(LDPCCode.TM8192, "f32", 524288, 2.0, id="config4-TM8192-f32-524288-per-gpu"),
+    pytest.param(LDPCCode.TM5120, "i8", 524288, 4.0, id="config5-TM5120-i8-524288-per-gpu"),
+]
+
+
+def _pool(code, count, seed):
+    rng = np.random.default_rng(seed)
+    pool = np.zeros((count, code.n() // 8), dtype=np.uint8)
+    for i in range(count):
+        code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
+    return pool
+
+
+def _hard_llrs(code, out, dtype):
+    """+-1 LLRs from packed output bits (MSB first), on the device, in chunks."""
+    n = code.n()
+    B = out.shape[0]
+    llrs = torch.empty((B, n), dtype=torch.float32 if dtype == "f32" else torch.int8, device=out.device)
+    shifts = torch.arange(7, -1, -1, device=out.device, dtype=torch.uint8)
+    step = 65536
+    for s in range(0, B, step):
+        bits = (out[s:s + step, : n // 8, None] >> shifts) & 1
+        llrs[s:s + step] = (1 - 2 * bits.reshape(-1, n).to(torch.int8)).to(llrs.dtype)
+    return llrs
+
+
+@pytest.mark.parametrize("code,dtype,frames,ebn0", CONFIGS)
+def test_full_batch_properties(code, dtype, frames, ebn0):
+    dev = torch.device("cuda", 0)
+    maxiters = 25
+    sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (ebn0 / 10.0))))
+    pool = _pool(code, 64, 0x1DBC + int(code))
+    d_pool = torch.from_numpy(pool).to(dev)
+    llrs = code.awgn_frames(d_pool, frames, sigma, seed=0x1DBC + int(code), dtype=dtype)
+    out, iters, ok = code.decode_ms_batch(llrs, maxiters)
+    torch.cuda.synchronize()
+
+    okb = ok.bool()
+    assert bool(((ok == 0) | (ok == 1)).all())
+    assert bool((iters[okb] < maxiters).all()) and bool((iters[~okb] == maxiters).all())
+
+    # determinism
+    out2, iters2, ok2 = code.decode_ms_batch(llrs, maxiters)
+    assert torch.equal(out, out2) and torch.equal(iters, iters2) and torch.equal(ok, ok2)
+
+    # batch-split invariance on an unaligned slice
+    a, b = frames // 3 + 1, frames // 3 + 1 + 4099
+    o_s, i_s, k_s = code.decode_ms_batch(llrs[a:b].contiguous(), maxiters)
+    assert torch.equal(o_s, out[a:b]) and torch.equal(i_s, iters[a:b]) and torch.equal(k_s, ok[a:b])
+
+    # oracle comparison on a sample (bit-exact), and the FER regime
+    sample = 2048 if code.n() <= 2048 else 384
+    h = llrs[:sample].cpu().numpy()
+    o_c, i_c, k_c, _ = oracle.decode_ms_batch(code, h, maxiters)
+    assert (out[:sample].cpu().numpy() == o_c).all()
+    assert (iters[:sample].cpu().numpy().astype(np.int64) == i_c.astype(np.int64)).all()
+    assert (ok[:sample].cpu().numpy() == k_c).all()
+    fer_gpu, fer_cpu = 1.0 - float(okb.float().mean()), 1.0 - float(k_c.mean())
+    assert abs(fer_gpu - fer_cpu) < 0.05 + 3 * np.sqrt(max(fer_cpu, 1e-3) / sample)
+
+    # successes decode to the transmitted codeword almost always; check they ARE codewords:
+    # idempotence of decode on its own successful outputs
+    del llrs
+    succ_idx = torch.nonzero(okb).flatten()
+    assert succ_idx.numel() > 0
+    clean = _hard_llrs(code, out[succ_idx], dtype)
+    o3, i3, k3 = code.decode_ms_batch(clean, maxiters)
+    torch.cuda.synchronize()
+    assert bool((k3 == 1).all())
+    assert bool((i3 <= (0 if code.punctured_bits() == 0 else 1)).all())
+    assert torch.equal(o3, out[succ_idx])
+
+    # and most successes equal the transmitted codeword (undetected errors are rare)
+    tx = d_pool[(succ_idx % d_pool.shape[0])]
+    same = (out[succ_idx][:, : code.n() // 8] == tx).all(dim=1).float().mean()
+    assert float(same) > 0.999
