@@ -40,6 +40,18 @@
 #include "codes.hpp"
 
 #define LDPC_INLINE __attribute__((always_inline))
+
+// Diagnostic switches for tools/kbench.hip only (timing experiments; results are wrong with them).
+#ifdef LDPC_DIAG_NOBARRIER
+#define LDPC_SYNC() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define LDPC_SYNC() __syncthreads()
+#endif
+#ifdef LDPC_DIAG_FIXED_ITERS
+#define LDPC_DIAG_EARLY_EXIT 0
+#else
+#define LDPC_DIAG_EARLY_EXIT 1
+#endif
 #define LDPC_DEV __device__ __forceinline__
 
 namespace ldpc {
@@ -50,6 +62,19 @@ template <int B, int E, class F>
 LDPC_DEV void static_for(F &&f)
 {
     if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+
+// XOR of D words with three-input XORs (v_bitop3_b32 issues at the fast VALU rate on gfx950)
+template <int D>
+LDPC_DEV int xor_reduce(const int (&w)[D])
+{
+    int acc = w[0];
+    static_for<0, (D - 1) / 2>([&](auto I_) LDPC_INLINE {
+        constexpr int i = 1 + 2 * decltype(I_)::value;
+        acc = __builtin_amdgcn_bitop3_b32(acc, w[i], w[i + 1], 0x96);
+    });
+    if constexpr (D % 2 == 0) acc ^= w[D - 1];
+    return acc;
 }
 
 // ---- prototype analysis -------------------------------------------------------------------
@@ -120,14 +145,70 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     LDPC_DEV static R add(R a, R b) { return a + b; }                           // :74
     LDPC_DEV static R sub(R a, R b) { return a - b; }                           // :75
     LDPC_DEV static R mag(R x) { return __builtin_fabsf(x); }                   // :73 (may be +inf)
-    LDPC_DEV static R min2(R a, R b) { return __builtin_fminf(a, b); }
-    LDPC_DEV static R min3(R a, R b, R c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+    // min of magnitudes.  AX/AY/AZ say whether the operand is a signed message whose magnitude is
+    // meant (the |x| source modifier is free) or already a magnitude.  Written as asm so that the
+    // operation tree of exclusive_min() is emitted as designed: through fminf() LLVM re-associates
+    // it into ~50 % more v_min ops plus canonicalising v_max ops.
+    template <bool AX, bool AY>
+    LDPC_DEV static R min2(R x, R y)
+    {
+        R d;
+        if constexpr (AX && AY) asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(d) : "v"(x), "v"(y));
+        else if constexpr (AX) asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(d) : "v"(x), "v"(y));
+        else if constexpr (AY) asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(d) : "v"(x), "v"(y));
+        else asm("v_min_f32_e32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+        return d;
+    }
+    // min(maxval, ...): the cap comes from an SGPR
+    template <bool AX>
+    LDPC_DEV static R min2_cap(R x)
+    {
+        R d;
+        const float cap = FLT_MAX;
+        if constexpr (AX) asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(d) : "v"(x), "s"(cap));
+        else asm("v_min_f32_e32 %0, %2, %1" : "=v"(d) : "v"(x), "s"(cap));
+        return d;
+    }
+    template <bool AX, bool AY>
+    LDPC_DEV static R min3_cap(R x, R y)
+    {
+        R d;
+        const float cap = FLT_MAX;
+        if constexpr (AX && AY) asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(d) : "v"(x), "v"(y), "s"(cap));
+        else if constexpr (!AX && !AY) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "s"(cap));
+        else d = min2_cap<false>(min2<AX, AY>(x, y));
+        return d;
+    }
+    template <bool AX, bool AY, bool AZ>
+    LDPC_DEV static R min3(R x, R y, R z)
+    {
+        R d;
+        if constexpr (AX && AY && AZ) asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+        else if constexpr (AX && AY) asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+        else if constexpr (!AX && !AY && !AZ) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+        else d = min2<false, AZ>(min2<AX, AY>(x, y), z);
+        return d;
+    }
     // magnitude `m` (>= 0) with the sign taken from bit 31 of `s`
     LDPC_DEV static R with_sign(R m, int s)
     {
         return __int_as_float((__float_as_int(m) & 0x7FFFFFFF) | (s & (int)0x80000000));
     }
     LDPC_DEV static R select_zero(bool z, R x) { return z ? 0.0f : x; }
+    // Self-correction test of decoder.rs:422: drop nv iff old != 0 and sign(nv) != sign(old).
+    // `old` with its sign flipped when nv is negative is a negative NON-ZERO float exactly then
+    // (old is never -0.0), so one three-input bit op (old ^ (nv & 0x80000000)) and one float
+    // compare decide it; "-0.0 < 0" is false, which is the old == 0 case.
+    LDPC_DEV static bool drop(R nv, R old)
+    {
+        const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
+        return __int_as_float(t) < 0.0f;
+    }
+    // m >= 0 has bit 31 clear, so "m with sign s_all ^ s_own" is one three-input XOR of sign words
+    LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
+    {
+        return __int_as_float(__builtin_amdgcn_bitop3_b32(__float_as_int(m), s_all, s_own, 0x96));
+    }
 };
 
 template <class I, int LO, int HI> struct IntOps {     // decoder.rs:42-59
@@ -142,10 +223,20 @@ template <class I, int LO, int HI> struct IntOps {     // decoder.rs:42-59
     LDPC_DEV static R add(R a, R b) { return clamp(a + b); }                    // saturating_add
     LDPC_DEV static R sub(R a, R b) { return clamp(a - b); }                    // saturating_sub
     LDPC_DEV static R mag(R x) { R a = x < 0 ? -x : x; return a > HI ? HI : a; } // saturating_abs
-    LDPC_DEV static R min2(R a, R b) { return a < b ? a : b; }
-    LDPC_DEV static R min3(R a, R b, R c) { return min2(min2(a, b), c); }
+    template <bool AX, bool AY>
+    LDPC_DEV static R min2(R x, R y)
+    {
+        const R a = AX ? mag(x) : x, b = AY ? mag(y) : y;
+        return a < b ? a : b;
+    }
+    template <bool AX, bool AY, bool AZ>
+    LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
+    template <bool AX> LDPC_DEV static R min2_cap(R x) { return AX ? mag(x) : x; }      // magnitudes are <= HI already
+    template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<AX, AY>(x, y); }
     LDPC_DEV static R with_sign(R m, int s) { return s < 0 ? -m : m; }
     LDPC_DEV static R select_zero(bool z, R x) { return z ? 0 : x; }
+    LDPC_DEV static bool drop(R nv, R old) { return ((nv ^ old) < 0) && (old != 0); }              // decoder.rs:422
+    LDPC_DEV static R apply_sign(R m, int s_all, int s_own) { return (s_all ^ s_own) < 0 ? -m : m; }
 };
 template <> struct Ops<int8_t>  : IntOps<int8_t, -128, 127> {};
 template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
@@ -155,7 +246,7 @@ template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
 // min1/min2 start at maxval (decoder.rs:414-415) and are only replaced by strictly smaller
 // values (:430-434), hence the clamp.  Elements are grouped in threes so that one min3 per
 // element finishes the job: ~1.7 operations per edge at degree 6, ~1.9 at degree 18.
-template <class O, int D>
+template <class O, int D, bool ABS>
 LDPC_DEV void exclusive_min(const typename O::R (&a)[D], typename O::R (&e)[D])
 {
     using R = typename O::R;
@@ -163,36 +254,54 @@ LDPC_DEV void exclusive_min(const typename O::R (&a)[D], typename O::R (&e)[D])
     if constexpr (D == 1) {
         e[0] = MX;
     } else if constexpr (D == 2) {
-        e[0] = O::min2(a[1], MX);
-        e[1] = O::min2(a[0], MX);
+        e[0] = O::template min2_cap<ABS>(a[1]);
+        e[1] = O::template min2_cap<ABS>(a[0]);
     } else if constexpr (D == 3) {
-        e[0] = O::min3(a[1], a[2], MX);
-        e[1] = O::min3(a[0], a[2], MX);
-        e[2] = O::min3(a[0], a[1], MX);
+        e[0] = O::template min3_cap<ABS, ABS>(a[1], a[2]);
+        e[1] = O::template min3_cap<ABS, ABS>(a[0], a[2]);
+        e[2] = O::template min3_cap<ABS, ABS>(a[0], a[1]);
     } else {
         constexpr int G = (D + 2) / 3;
         R t[G], x[G];
         static_for<0, G>([&](auto g_) LDPC_INLINE {
             constexpr int g = decltype(g_)::value, n = (3 * g + 3 <= D) ? 3 : D - 3 * g;
-            if constexpr (n == 3) t[g] = O::min3(a[3 * g], a[3 * g + 1], a[3 * g + 2]);
-            else if constexpr (n == 2) t[g] = O::min2(a[3 * g], a[3 * g + 1]);
-            else t[g] = a[3 * g];
+            if constexpr (n == 3) t[g] = O::template min3<ABS, ABS, ABS>(a[3 * g], a[3 * g + 1], a[3 * g + 2]);
+            else if constexpr (n == 2) t[g] = O::template min2<ABS, ABS>(a[3 * g], a[3 * g + 1]);
+            else t[g] = ABS ? O::mag(a[3 * g]) : a[3 * g];
         });
-        exclusive_min<O, G>(t, x);
+        exclusive_min<O, G, false>(t, x);
         static_for<0, G>([&](auto g_) LDPC_INLINE {
             constexpr int g = decltype(g_)::value, n = (3 * g + 3 <= D) ? 3 : D - 3 * g;
             if constexpr (n == 3) {
-                e[3 * g]     = O::min3(a[3 * g + 1], a[3 * g + 2], x[g]);
-                e[3 * g + 1] = O::min3(a[3 * g],     a[3 * g + 2], x[g]);
-                e[3 * g + 2] = O::min3(a[3 * g],     a[3 * g + 1], x[g]);
+                e[3 * g]     = O::template min3<ABS, ABS, false>(a[3 * g + 1], a[3 * g + 2], x[g]);
+                e[3 * g + 1] = O::template min3<ABS, ABS, false>(a[3 * g],     a[3 * g + 2], x[g]);
+                e[3 * g + 2] = O::template min3<ABS, ABS, false>(a[3 * g],     a[3 * g + 1], x[g]);
             } else if constexpr (n == 2) {
-                e[3 * g]     = O::min2(a[3 * g + 1], x[g]);
-                e[3 * g + 1] = O::min2(a[3 * g],     x[g]);
+                e[3 * g]     = O::template min2<ABS, false>(a[3 * g + 1], x[g]);
+                e[3 * g + 1] = O::template min2<ABS, false>(a[3 * g],     x[g]);
             } else {
                 e[3 * g] = x[g];
             }
         });
     }
+}
+
+// ---- LDS layout of one codeword: [ first half of the xu slots | xva columns | rest of xu | flags ]
+constexpr int lds_xu_off(const Prototype &p, int slot, int blk_bytes)
+{
+    const int lo = (count_exchanged(p) + 1) / 2;
+    return (slot < lo ? slot : slot + count_exch_cols(p)) * blk_bytes;
+}
+constexpr int lds_xva_off(const Prototype &p, int cs, int blk_bytes)
+{
+    return ((count_exchanged(p) + 1) / 2 + cs) * blk_bytes;
+}
+// lower of the two region offsets an exchanged block b touches (folded into its address register)
+constexpr int lds_bias(const Prototype &p, int b, int blk_bytes)
+{
+    const int a0 = lds_xu_off(p, exch_slot(p, b), blk_bytes);
+    const int a1 = lds_xva_off(p, col_slot(p, p.blk[b].col), blk_bytes);
+    return a0 < a1 ? a0 : a1;
 }
 
 // ---- kernel geometry -----------------------------------------------------------------------
@@ -245,7 +354,12 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     //   xva  marginals of the block columns those blocks touch
     //   flag "some parity check failed", double-buffered over iterations
     constexpr int SZ = sizeof(T);
-    constexpr int XVA_OFF = NX * M * SZ, FLAG_OFF = (NX + NXC) * M * SZ;
+    // The xva regions sit in the middle of the xu slots so that, for every exchanged edge, its xu
+    // slot and its xva column are less than 64 KB apart: one address register (biased by the
+    // lower of the two region offsets, lds_bias()) then serves both accesses through the 16-bit
+    // instruction offset.
+    constexpr int FLAG_OFF = (NX + NXC) * M * SZ;
+    constexpr int BLK_BYTES = M * SZ;
     constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) char lds[G * GROUP_BYTES];
 
@@ -257,6 +371,13 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     const bool live = cw < batch;
     char *const gbase = lds + (G == 1 ? 0 : grp * GROUP_BYTES);
     auto lds_at = [&](int byte_off) LDPC_INLINE -> T & { return *reinterpret_cast<T *>(gbase + byte_off); };
+#ifdef LDPC_DIAG_NOLDS
+    auto lds_load = [&](int byte_off) LDPC_INLINE -> T { T r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(byte_off)); return r; };
+    auto lds_store = [&](int byte_off, T val) LDPC_INLINE { asm volatile("" ::"v"(byte_off), "v"(val)); };
+#else
+    auto lds_load = [&](int byte_off) LDPC_INLINE -> T { return lds_at(byte_off); };
+    auto lds_store = [&](int byte_off, T val) LDPC_INLINE { lds_at(byte_off) = val; };
+#endif
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
@@ -280,7 +401,8 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                     const int j = S * (NT / Q) + jw;
                     const int phi = j == 0 ? phi_of(K, 0, M) : (j == 1 ? phi_of(K, 1, M) : (j == 2 ? phi_of(K, 2, M) : phi_of(K, 3, M)));
                     rot_s[S][B] = (phi + S * NT) * SZ;
-                    base_s[S][B] = (((theta_of(K) + j) & 3) << LQ) * SZ;
+                    constexpr int bias = lds_bias(P, B, BLK_BYTES);
+                    base_s[S][B] = (((theta_of(K) + j) & 3) << LQ) * SZ + bias;
                 }
             });
         });
@@ -288,15 +410,16 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     auto wire = [&](auto B_, auto S_, int tb) LDPC_INLINE -> int {
         constexpr int B = decltype(B_)::value, S = decltype(S_)::value;
         constexpr Block blk = P.blk[B];
+        constexpr int bias = lds_bias(P, B, BLK_BYTES);
         if constexpr (blk.kind == BLK_I) {
-            return (tb + (S * NT + blk.val) * SZ) & (M * SZ - 1);
+            return ((tb + (S * NT + blk.val) * SZ) & (M * SZ - 1)) | bias;
         } else if constexpr (QUARTER_LITERAL) {
             constexpr int j = (S * NT) / Q, K = blk.val;
-            return ((tb + (phi_of(K, j, M) + S * NT) * SZ) & (Q * SZ - 1)) | ((((theta_of(K) + j) & 3) << LQ) * SZ);
+            return ((tb + (phi_of(K, j, M) + S * NT) * SZ) & (Q * SZ - 1)) | ((((theta_of(K) + j) & 3) << LQ) * SZ + bias);
         } else if constexpr (QUARTER_SCALAR) {
             return ((tb + rot_s[S][B]) & (Q * SZ - 1)) | base_s[S][B];
         } else {
-            return pi_dev<blk.val, M>(S * NT + tb / SZ, (S * NT + tb / SZ) >> LQ) * SZ;
+            return pi_dev<blk.val, M>(S * NT + tb / SZ, (S * NT + tb / SZ) >> LQ) * SZ + bias;
         }
     };
 
@@ -314,7 +437,10 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
             u[S][B] = O::zero();                                               // decoder.rs:374
             v[S][B] = O::zero();
             constexpr int slot = exch_slot(P, B);
-            if constexpr (slot >= 0) lds_at(slot * M * SZ + wire(B_, S_, t * SZ)) = O::store(O::zero());
+            if constexpr (slot >= 0) {
+                constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                lds_store(off + wire(B_, S_, t * SZ), O::store(O::zero()));
+            }
         });
         static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
         static_for<0, NTX>([&](auto C_) LDPC_INLINE {
@@ -338,13 +464,19 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                     constexpr int B = decltype(B_)::value;
                     if constexpr (P.blk[B].col == C) {
                         constexpr int slot = exch_slot(P, B);
-                        if constexpr (slot >= 0) acc = O::add(acc, O::from_lds(lds_at(slot * M * SZ + i * SZ)));
+                        if constexpr (slot >= 0) {
+                            constexpr int off = lds_xu_off(P, slot, BLK_BYTES);
+                            acc = O::add(acc, O::from_lds(lds_load(off + i * SZ)));
+                        }
                         else acc = O::add(acc, u[S][B]);
                     }
                 });
                 va[S][C] = acc;
                 constexpr int cs = col_slot(P, C);
-                if constexpr (cs >= 0) lds_at(XVA_OFF + cs * M * SZ + i * SZ) = O::store(acc);
+                if constexpr (cs >= 0) {
+                    constexpr int off = lds_xva_off(P, cs, BLK_BYTES);
+                    lds_store(off + i * SZ, O::store(acc));
+                }
             });
         });
     };
@@ -359,38 +491,54 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         asm volatile("" : "+v"(tb));
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             constexpr int S = decltype(S_)::value;
+            // the marginals of this index's exchanged edges are requested from LDS up front so
+            // that their latency overlaps the local-edge arithmetic of the first rows
+            R xs[1][NB];
+            int ad[1][NB];
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int B = decltype(B_)::value;
+                constexpr int slot = exch_slot(P, B);
+                if constexpr (slot >= 0) {
+                    constexpr int cs = col_slot(P, P.blk[B].col);
+                    constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                    ad[0][B] = wire(B_, S_, tb);
+                    xs[0][B] = O::from_lds(lds_load(off + ad[0][B]));
+                }
+            });
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
                 R a[D], e[D];
-                int sgn = 0, par = 0;
+                int sw[D], xw[D];         // sign words of the new v (bit 31 only) / patterns of the marginals
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
                     constexpr Block blk = P.blk[B];
                     constexpr int slot = exch_slot(P, B);
-                    constexpr int cs = col_slot(P, blk.col);
                     R x;
-                    if constexpr (slot >= 0) x = O::from_lds(lds_at(XVA_OFF + cs * M * SZ + wire(IC<B>{}, S_, tb)));
+                    if constexpr (slot >= 0) x = xs[0][B];
                     else x = va[S][blk.col];
                     const R nv = O::sub(x, u[S][B]);                                   // :421
                     const R old = v[S][B];
                     // keep nv if its sign equals old's or old is zero, else zero it (:422-425)
-                    const bool drop = ((O::bits(nv) ^ O::bits(old)) < 0) && (O::bits(old) != 0);
-                    const R nw = O::select_zero(drop, nv);
+                    const R nw = O::select_zero(O::drop(nv, old), nv);
                     v[S][B] = nw;
-                    a[J] = O::mag(nw);
-                    sgn ^= O::bits(nw);                                                // :439-441
-                    par ^= O::bits(x);                                                 // :445-447
+                    a[J] = nw;                                                         // magnitude taken in exclusive_min
+                    sw[J] = O::bits(nw) & (int)0x80000000;                             // :439-441
+                    xw[J] = O::bits(x);                                                // :445-447
                 });
-                exclusive_min<O, D>(a, e);                                             // :391-395, :430-435
+                const int sgn = xor_reduce<D>(sw), par = xor_reduce<D>(xw);
+                exclusive_min<O, D, true>(a, e);                                             // :391-395, :430-435
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
-                    const R un = O::with_sign(e[J], sgn ^ O::bits(v[S][B]));           // :398-405
+                    const R un = O::apply_sign(e[J], sgn, sw[J]);                      // :398-405
                     u[S][B] = un;
                     constexpr int slot = exch_slot(P, B);
-                    if constexpr (slot >= 0) lds_at(slot * M * SZ + wire(IC<B>{}, S_, tb)) = O::store(un);
+                    if constexpr (slot >= 0) {
+                        constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                        lds_store(off + ad[0][B], O::store(un));
+                    }
                 });
                 par_any |= par;
             });
@@ -403,17 +551,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     bool done = false, ok = false;
     uint32_t iters = maxiters;
     for (uint32_t it = 0;; ++it) {
-        __syncthreads();          // u of the exchanged blocks and the parity vote are visible
+        LDPC_SYNC();              // u of the exchanged blocks and the parity vote are visible
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
-            if (it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
+            if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
             else if (it == maxiters) { done = true; }
         }
         if constexpr (G == 1) { if (done) break; }
         else { if (__all(done)) break; }
 
         if (G == 1 || !done) variable_phase();
-        __syncthreads();
+        LDPC_SYNC();
         if (it > 0 && t == 0) flag_at(it - 1) = 0;
         if (G == 1 || !done) check_phase(it);
     }

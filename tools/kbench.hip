@@ -1,0 +1,58 @@
+// kbench.hip -- quick kernel-only timing loop for decode_ms_kernel experiments (development tool).
+// On the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-fast-math -ffp-contract=off -fno-slp-vectorize \
+//                  -Ilabrador_ldpc_amd/csrc [-DKCODE=8 -DKIPT=2 -DKFRAMES=131072] -o /tmp/kbench tools/kbench.hip labrador_ldpc_amd/csrc/channel.hip && /tmp/kbench
+// Frames: all-zero codeword (valid for a linear code; min-sum is symmetric) + AWGN at 2 dB.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "decode_ms_kernel.hpp"
+#include "channel.hpp"
+#ifndef KCODE
+#define KCODE 8
+#endif
+#ifndef KIPT
+#define KIPT 2
+#endif
+#ifndef KFRAMES
+#define KFRAMES 131072
+#endif
+#ifndef KMAXIT
+#define KMAXIT 25
+#endif
+#ifndef KEBN0
+#define KEBN0 2.0
+#endif
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main()
+{
+    using namespace ldpc;
+    constexpr int code = KCODE;
+    const CodeInfo &ci = CODES[code];
+    const size_t F = KFRAMES, n = ci.n, ol = ci.output_len();
+    const float sigma = (float)std::sqrt(1.0 / (2.0 * ((double)ci.k / ci.n) * std::pow(10.0, KEBN0 / 10.0)));
+    uint8_t *pool; float *llrs; uint8_t *out, *ok; uint32_t *iters;
+    CK(hipMalloc(&pool, n / 8)); CK(hipMemset(pool, 0, n / 8));
+    CK(hipMalloc(&llrs, F * n * 4)); CK(hipMalloc(&out, F * ol)); CK(hipMalloc(&ok, F)); CK(hipMalloc(&iters, F * 4));
+    CK(launch_awgn<float>(pool, 1, llrs, (int)n, F, sigma, 1.f, 0, 0x1DBCull + code, nullptr));
+    using GEO = Geometry<code, float, KIPT>;
+    const unsigned groups = (unsigned)((F + GEO::G - 1) / GEO::G);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((decode_ms_kernel<code, float, KIPT>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    std::vector<uint32_t> hi(F); std::vector<uint8_t> hk(F), ho(F * ol);
+    CK(hipMemcpy(hi.data(), iters, F * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hk.data(), ok, F, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ho.data(), out, F * ol, hipMemcpyDeviceToHost));
+    double si = 0, sk = 0; unsigned long long h = 1469598103934665603ull;
+    for (size_t f = 0; f < F; ++f) { si += hi[f]; sk += hk[f]; h = (h ^ hi[f] ^ ((unsigned long long)hk[f] << 32)) * 1099511628211ull; }
+    for (size_t i = 0; i < F * ol; ++i) h = (h ^ ho[i]) * 1099511628211ull;
+    printf("code %d ipt %d frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", code, KIPT, F, best,
+           F / best / 1e3, si / F, sk / F, h);
+    return 0;
+}
