@@ -45,7 +45,9 @@
 #ifdef LDPC_DIAG_NOBARRIER
 #define LDPC_SYNC() __builtin_amdgcn_s_waitcnt(0)
 #else
-#define LDPC_SYNC() __syncthreads()
+// Workgroup barrier for LDS hand-offs.  Written out (instead of __syncthreads()) so that it waits
+// for LDS operations only and not for the asynchronous LLR staging copies counted in vmcnt.
+#define LDPC_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 #ifdef LDPC_DIAG_FIXED_ITERS
 #define LDPC_DIAG_EARLY_EXIT 0
@@ -335,7 +337,9 @@ LDPC_DEV int pi_dev(int i, int j)
     return (((TH + j) & 3) << LQ) + ((phi + i) & (Q - 1));
 }
 
-template <int CODE, class T, int IPT>
+// PF: stage the NEXT codeword's LLRs in LDS with asynchronous global->LDS loads while the current
+// one is being decoded (costs n*sizeof(T) bytes of LDS; used where one workgroup fills the CU).
+template <int CODE, class T, int IPT, bool PF>
 __global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
@@ -361,14 +365,19 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     constexpr int FLAG_OFF = (NX + NXC) * M * SZ;
     constexpr int BLK_BYTES = M * SZ;
     constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16;
+    static_assert(!PF || (G == 1 && NT >= 64), "LLR staging needs whole waves per codeword");
+    constexpr int STAGE_BYTES = PF ? N * SZ : 0;
     __shared__ __attribute__((aligned(16))) char lds[G * GROUP_BYTES];
+    __shared__ __attribute__((aligned(16))) char stage[PF ? STAGE_BYTES : 16];   // own object: see stage_issue()
 
     const int tid = threadIdx.x;
     const int grp = G == 1 ? 0 : tid / NT;
     const int t = G == 1 ? tid : tid % NT;
     __builtin_assume(t >= 0 && t < NT);
-    const uint32_t cw = blockIdx.x * G + grp;
-    const bool live = cw < batch;
+    // Persistent workgroups: workgroup b decodes codeword groups b, b + gridDim.x, ...
+    const uint32_t n_groups = (batch + G - 1) / G;
+    uint32_t cw = blockIdx.x * G + grp;
+    bool live = cw < batch;
     char *const gbase = lds + (G == 1 ? 0 : grp * GROUP_BYTES);
     auto lds_at = [&](int byte_off) LDPC_INLINE -> T & { return *reinterpret_cast<T *>(gbase + byte_off); };
 #ifdef LDPC_DIAG_NOLDS
@@ -429,26 +438,59 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     R va[IPT][NCOLS];             // marginals                                  (decoder.rs:377)
     R llr[IPT][NTX];              // channel LLRs, read from HBM once
 
-    static_for<0, IPT>([&](auto S_) LDPC_INLINE {
-        constexpr int S = decltype(S_)::value;
-        const int i = S * NT + t;
-        static_for<0, NB>([&](auto B_) LDPC_INLINE {
-            constexpr int B = decltype(B_)::value;
-            u[S][B] = O::zero();                                               // decoder.rs:374
-            v[S][B] = O::zero();
-            constexpr int slot = exch_slot(P, B);
-            if constexpr (slot >= 0) {
-                constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
-                lds_store(off + wire(B_, S_, t * SZ), O::store(O::zero()));
-            }
+    // Asynchronous global -> LDS copy of codeword `c`'s LLRs into the staging buffer.  Each wave
+    // stages exactly the elements its own lanes will read back, so only the issuing wave's
+    // vmcnt has to be waited for, never a barrier.  `stage` is a separate __shared__ object so
+    // that the compiler does not order the decode loop's LDS traffic behind these copies.
+    auto stage_issue = [&](uint32_t c) LDPC_INLINE {
+        if constexpr (PF) {
+            unsigned tu = (unsigned)t;
+            asm volatile("" : "+v"(tu));
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                    constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
+                    const T *src = (llrs + (size_t)c * N) + ((unsigned)(C * M + S * NT) + tu);   // scalar base + lane offset
+                    char *dst = stage + (C * M + S * NT + (t & ~63)) * SZ;           // wave-uniform
+                    auto gsrc = (const __attribute__((address_space(1))) void *)src;
+                    auto ldst = (__attribute__((address_space(3))) void *)dst;
+                    // the size operand must be a literal
+                    if constexpr (SZ == 4) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 0, 0);
+                    else if constexpr (SZ == 2) __builtin_amdgcn_global_load_lds(gsrc, ldst, 2, 0, 0);
+                    else __builtin_amdgcn_global_load_lds(gsrc, ldst, 1, 0, 0);
+                });
+            });
+        }
+    };
+
+    auto begin_codeword = [&](bool staged) LDPC_INLINE {
+        if constexpr (PF) {
+            if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        int tb = t * SZ;
+        unsigned tu = (unsigned)t;
+        asm volatile("" : "+v"(tb), "+v"(tu));   // keep the address arithmetic inside the loop (see check_phase)
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value;
+            const int i = S * NT + t;
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int B = decltype(B_)::value;
+                u[S][B] = O::zero();                                               // decoder.rs:374
+                v[S][B] = O::zero();
+                constexpr int slot = exch_slot(P, B);
+                if constexpr (slot >= 0) {
+                    constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                    lds_store(off + wire(B_, S_, tb), O::store(O::zero()));
+                }
+            });
+            static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
+            static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                constexpr int C = decltype(C_)::value;
+                if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * SZ));
+                else llr[S][C] = live ? O::load((llrs + (size_t)cw * N)[(unsigned)(C * M + S * NT) + tu]) : O::zero();
+            });
         });
-        static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
-        static_for<0, NTX>([&](auto C_) LDPC_INLINE {
-            constexpr int C = decltype(C_)::value;
-            llr[S][C] = live ? O::load(llrs[(size_t)cw * N + C * M + i]) : O::zero();
-        });
-    });
-    if (t < 2) flag_at(t) = 0;
+        if (t < 2) flag_at(t) = 0;
+    };
 
     // One iteration of message passing for this thread's indices: the two phases below.
     auto variable_phase = [&]() LDPC_INLINE {
@@ -546,6 +588,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         if (par_any < 0) flag_at(it) = 1;
     };
 
+    for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
+    cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
+    live = cw < batch;
+    begin_codeword(!first);
+    if constexpr (PF) {
+        // the staged LLRs are in registers (the loads above were waited for by their use in
+        // O::load's consumers only after lgkmcnt; make that explicit), now refill the stage
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (g + gridDim.x < n_groups) stage_issue((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
+    }
+
     // Codewords that share a wave (G > 1) finish at different iterations: a finished one
     // simply stops updating (its lanes are masked off) until the whole wave is done.
     bool done = false, ok = false;
@@ -579,7 +632,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
             });
         });
         if ((tid & 63) == 0) {
-            uint8_t *dst = output + (size_t)cw * GEO::OUT_LEN + t / 8;
+            uint8_t *dst = (output + (size_t)cw * GEO::OUT_LEN) + t / 8;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
                     constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
@@ -599,6 +652,8 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         });
     }
     if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
+    LDPC_SYNC();                  // every wave is done with the flags before the next codeword resets them
+    }                             // persistent loop over codeword groups
 }
 
 
