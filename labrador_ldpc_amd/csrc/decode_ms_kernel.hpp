@@ -531,55 +531,71 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         // then stay live across the whole loop (which costs more in spills than it saves).
         int tb = t * SZ;
         asm volatile("" : "+v"(tb));
+        // Order of work, chosen so that LDS latency is covered by arithmetic: (1) request the
+        // marginals of all exchanged edges, (2) update the LOCAL edges (their marginals are in
+        // registers), (3) update the exchanged edges as their data arrives, (4) per check:
+        // exclusive minima, signs, next u, and the LDS stores of the exchanged u.
+        R xs[IPT][NB];
+        int ad[IPT][NB];
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
-            constexpr int S = decltype(S_)::value;
-            // the marginals of this index's exchanged edges are requested from LDS up front so
-            // that their latency overlaps the local-edge arithmetic of the first rows
-            R xs[1][NB];
-            int ad[1][NB];
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
-                constexpr int B = decltype(B_)::value;
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 constexpr int slot = exch_slot(P, B);
                 if constexpr (slot >= 0) {
                     constexpr int cs = col_slot(P, P.blk[B].col);
                     constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
-                    ad[0][B] = wire(B_, S_, tb);
-                    xs[0][B] = O::from_lds(lds_load(off + ad[0][B]));
+                    ad[S][B] = wire(B_, S_, tb);
+                    xs[S][B] = O::from_lds(lds_load(off + ad[S][B]));
                 }
             });
+        });
+        __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
+        auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+            const R nv = O::sub(x, u[S][B]);                                           // :421
+            // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
+            const R nw = O::select_zero(O::drop(nv, v[S][B]), nv);
+            v[S][B] = nw;
+        };
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2)
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col]);
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B]);
+            });
+        });
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (4)
+            constexpr int S = decltype(S_)::value;
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
                 R a[D], e[D];
-                int sw[D], xw[D];         // sign words of the new v (bit 31 only) / patterns of the marginals
+                int sr[D], xw[D];
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
-                    constexpr Block blk = P.blk[B];
-                    constexpr int slot = exch_slot(P, B);
-                    R x;
-                    if constexpr (slot >= 0) x = xs[0][B];
-                    else x = va[S][blk.col];
-                    const R nv = O::sub(x, u[S][B]);                                   // :421
-                    const R old = v[S][B];
-                    // keep nv if its sign equals old's or old is zero, else zero it (:422-425)
-                    const R nw = O::select_zero(O::drop(nv, old), nv);
-                    v[S][B] = nw;
-                    a[J] = nw;                                                         // magnitude taken in exclusive_min
-                    sw[J] = O::bits(nw) & (int)0x80000000;                             // :439-441
-                    xw[J] = O::bits(x);                                                // :445-447
+                    a[J] = v[S][B];                                                    // magnitude taken in exclusive_min
+                    sr[J] = O::bits(v[S][B]) & (int)0x80000000;                        // sign word, :439-441
+                    if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
+                    else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
-                const int sgn = xor_reduce<D>(sw), par = xor_reduce<D>(xw);
-                exclusive_min<O, D, true>(a, e);                                             // :391-395, :430-435
+                const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
+                exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
-                    const R un = O::apply_sign(e[J], sgn, sw[J]);                      // :398-405
+                    const R un = O::apply_sign(e[J], sgn, sr[J]);                      // :398-405
                     u[S][B] = un;
                     constexpr int slot = exch_slot(P, B);
                     if constexpr (slot >= 0) {
                         constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
-                        lds_store(off + ad[0][B], O::store(un));
+                        lds_store(off + ad[S][B], O::store(un));
                     }
                 });
                 par_any |= par;
