@@ -14,10 +14,10 @@ hipError_t launch_decode_ms<float>(int code, int variant, const float *llrs, uin
         LDPC_CASE(TC256,  float, 1)
         LDPC_CASE(TC512,  float, 1)
         LDPC_CASE(TM1280, float, 1)
-        LDPC_CASE(TM1536, float, 2)
-        LDPC_CASE(TM2048, float, 2, 4)
+        LDPC_CASE(TM1536, float, 1, 2)
+        LDPC_CASE(TM2048, float, 1, 2)
         LDPC_CASE(TM5120, float, 1)
-        LDPC_CASE(TM6144, float, 2)
+        LDPC_CASE(TM6144, float, 1, 2)
         LDPC_CASE(TM8192, float, 2, 4)
         default: return hipErrorInvalidValue;
     }

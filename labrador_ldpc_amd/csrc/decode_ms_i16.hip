@@ -14,11 +14,11 @@ hipError_t launch_decode_ms<int16_t>(int code, int variant, const int16_t *llrs,
         LDPC_CASE(TC256,  int16_t, 1)
         LDPC_CASE(TC512,  int16_t, 1)
         LDPC_CASE(TM1280, int16_t, 1)
-        LDPC_CASE(TM1536, int16_t, 2)
-        LDPC_CASE(TM2048, int16_t, 4)
+        LDPC_CASE(TM1536, int16_t, 1, 2)
+        LDPC_CASE(TM2048, int16_t, 1)
         LDPC_CASE(TM5120, int16_t, 1)
-        LDPC_CASE(TM6144, int16_t, 2)
-        LDPC_CASE(TM8192, int16_t, 4)
+        LDPC_CASE(TM6144, int16_t, 1, 2)
+        LDPC_CASE(TM8192, int16_t, 2)
         default: return hipErrorInvalidValue;
     }
 }

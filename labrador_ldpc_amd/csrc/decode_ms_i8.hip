@@ -14,11 +14,11 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
         LDPC_CASE(TC256,  int8_t, 1)
         LDPC_CASE(TC512,  int8_t, 1)
         LDPC_CASE(TM1280, int8_t, 1)
-        LDPC_CASE(TM1536, int8_t, 2)
-        LDPC_CASE(TM2048, int8_t, 4)
-        LDPC_CASE(TM5120, int8_t, 1, 2)
-        LDPC_CASE(TM6144, int8_t, 2)
-        LDPC_CASE(TM8192, int8_t, 4)
+        LDPC_CASE(TM1536, int8_t, 1, 2)
+        LDPC_CASE(TM2048, int8_t, 1)
+        LDPC_CASE(TM5120, int8_t, 1)
+        LDPC_CASE(TM6144, int8_t, 1, 2)
+        LDPC_CASE(TM8192, int8_t, 2)
         default: return hipErrorInvalidValue;
     }
 }

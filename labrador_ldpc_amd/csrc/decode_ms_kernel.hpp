@@ -137,7 +137,8 @@ constexpr int row_block(const Prototype &p, int row, int j)
 template <class T> struct Ops;
 
 template <> struct Ops<float> {                       // decoder.rs:69-77
-    using R = float;
+    using R = float;                                   // register type
+    using E = float;                                   // LDS exchange element type
     LDPC_DEV static R zero() { return 0.0f; }
     LDPC_DEV static R maxval() { return FLT_MAX; }                              // :72
     LDPC_DEV static R load(float x) { return x + 0.0f; }                        // -0.0 -> +0.0
@@ -213,32 +214,37 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     }
 };
 
-template <class I, int LO, int HI> struct IntOps {     // decoder.rs:42-59
-    using R = int;
-    LDPC_DEV static R zero() { return 0; }
-    LDPC_DEV static R maxval() { return HI; }
-    LDPC_DEV static R load(I x) { return (int)x; }
-    LDPC_DEV static I store(R x) { return (I)x; }
-    LDPC_DEV static R from_lds(I x) { return (int)x; }
-    LDPC_DEV static int bits(R x) { return x; }
-    LDPC_DEV static R clamp(R x) { return x < LO ? LO : (x > HI ? HI : x); }
+// Integer LLR types run on the float pipeline: i8/i16 values and every intermediate of the
+// algorithm are integers of magnitude <= 2^16, which f32 represents exactly, so saturating
+// add/sub (decoder.rs:47-48, :56-57) are an f32 add/sub followed by a clamp, and all the sign-bit
+// and exclusive-minimum machinery of the f32 path applies unchanged.  saturating_abs(-2^(b-1)) =
+// 2^(b-1)-1 (decoder.rs:46, :55) falls out of capping the exclusive minimum at maxval.
+template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.rs:42-59
+    LDPC_DEV static R maxval() { return (float)HI; }
+    LDPC_DEV static R load(I x) { return (float)(int)x; }                       // never -0.0
+    LDPC_DEV static R clamp(R x) { return __builtin_amdgcn_fmed3f(x, (float)LO, (float)HI); }
     LDPC_DEV static R add(R a, R b) { return clamp(a + b); }                    // saturating_add
     LDPC_DEV static R sub(R a, R b) { return clamp(a - b); }                    // saturating_sub
-    LDPC_DEV static R mag(R x) { R a = x < 0 ? -x : x; return a > HI ? HI : a; } // saturating_abs
-    template <bool AX, bool AY>
-    LDPC_DEV static R min2(R x, R y)
+    LDPC_DEV static R mag(R x) { return __builtin_fminf(__builtin_fabsf(x), (float)HI); }   // saturating_abs
+    template <bool AX>
+    LDPC_DEV static R min2_cap(R x)
     {
-        const R a = AX ? mag(x) : x, b = AY ? mag(y) : y;
-        return a < b ? a : b;
+        R d;
+        const float cap = (float)HI;
+        if constexpr (AX) asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(d) : "v"(x), "s"(cap));
+        else asm("v_min_f32_e32 %0, %2, %1" : "=v"(d) : "v"(x), "s"(cap));
+        return d;
     }
-    template <bool AX, bool AY, bool AZ>
-    LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
-    template <bool AX> LDPC_DEV static R min2_cap(R x) { return AX ? mag(x) : x; }      // magnitudes are <= HI already
-    template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<AX, AY>(x, y); }
-    LDPC_DEV static R with_sign(R m, int s) { return s < 0 ? -m : m; }
-    LDPC_DEV static R select_zero(bool z, R x) { return z ? 0 : x; }
-    LDPC_DEV static bool drop(R nv, R old) { return ((nv ^ old) < 0) && (old != 0); }              // decoder.rs:422
-    LDPC_DEV static R apply_sign(R m, int s_all, int s_own) { return (s_all ^ s_own) < 0 ? -m : m; }
+    template <bool AX, bool AY>
+    LDPC_DEV static R min3_cap(R x, R y)
+    {
+        R d;
+        const float cap = (float)HI;
+        if constexpr (AX && AY) asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(d) : "v"(x), "v"(y), "s"(cap));
+        else if constexpr (!AX && !AY) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "s"(cap));
+        else d = min2_cap<false>(Ops<float>::min2<AX, AY>(x, y));
+        return d;
+    }
 };
 template <> struct Ops<int8_t>  : IntOps<int8_t, -128, 127> {};
 template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
@@ -320,7 +326,7 @@ struct Geometry {
     static constexpr int NX = count_exchanged(*CODES[CODE].proto);
     static constexpr int NXC = count_exch_cols(*CODES[CODE].proto);
     static constexpr int OUT_LEN = CODES[CODE].output_len();
-    static constexpr size_t LDS_BYTES = (size_t)G * (NX + NXC) * M * sizeof(T) + G * 2 * sizeof(int);
+    static constexpr size_t LDS_BYTES = (size_t)G * (NX + NXC) * M * sizeof(typename Ops<T>::E) + G * 2 * sizeof(int);
     static_assert(M % IPT == 0 && NT >= 8 && (NT & (NT - 1)) == 0, "bad IPT");
 };
 
@@ -357,7 +363,8 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     //   xu   check -> variable messages of the exchanged blocks, stored at the VARIABLE's index
     //   xva  marginals of the block columns those blocks touch
     //   flag "some parity check failed", double-buffered over iterations
-    constexpr int SZ = sizeof(T);
+    using E = typename O::E;
+    constexpr int SZ = sizeof(E);             // LDS element size (HBM elements are sizeof(T))
     // The xva regions sit in the middle of the xu slots so that, for every exchanged edge, its xu
     // slot and its xva column are less than 64 KB apart: one address register (biased by the
     // lower of the two region offsets, lds_bias()) then serves both accesses through the 16-bit
@@ -366,7 +373,8 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     constexpr int BLK_BYTES = M * SZ;
     constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16;
     static_assert(!PF || (G == 1 && NT >= 64), "LLR staging needs whole waves per codeword");
-    constexpr int STAGE_BYTES = PF ? N * SZ : 0;
+    constexpr int TSZ = sizeof(T);
+    constexpr int STAGE_BYTES = PF ? N * TSZ : 0;
     __shared__ __attribute__((aligned(16))) char lds[G * GROUP_BYTES];
     __shared__ __attribute__((aligned(16))) char stage[PF ? STAGE_BYTES : 16];   // own object: see stage_issue()
 
@@ -379,13 +387,13 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     uint32_t cw = blockIdx.x * G + grp;
     bool live = cw < batch;
     char *const gbase = lds + (G == 1 ? 0 : grp * GROUP_BYTES);
-    auto lds_at = [&](int byte_off) LDPC_INLINE -> T & { return *reinterpret_cast<T *>(gbase + byte_off); };
+    auto lds_at = [&](int byte_off) LDPC_INLINE -> E & { return *reinterpret_cast<E *>(gbase + byte_off); };
 #ifdef LDPC_DIAG_NOLDS
-    auto lds_load = [&](int byte_off) LDPC_INLINE -> T { T r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(byte_off)); return r; };
-    auto lds_store = [&](int byte_off, T val) LDPC_INLINE { asm volatile("" ::"v"(byte_off), "v"(val)); };
+    auto lds_load = [&](int byte_off) LDPC_INLINE -> E { E r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(byte_off)); return r; };
+    auto lds_store = [&](int byte_off, E val) LDPC_INLINE { asm volatile("" ::"v"(byte_off), "v"(val)); };
 #else
-    auto lds_load = [&](int byte_off) LDPC_INLINE -> T { return lds_at(byte_off); };
-    auto lds_store = [&](int byte_off, T val) LDPC_INLINE { lds_at(byte_off) = val; };
+    auto lds_load = [&](int byte_off) LDPC_INLINE -> E { return lds_at(byte_off); };
+    auto lds_store = [&](int byte_off, E val) LDPC_INLINE { lds_at(byte_off) = val; };
 #endif
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
@@ -450,12 +458,12 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                 static_for<0, NTX>([&](auto C_) LDPC_INLINE {
                     constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
                     const T *src = (llrs + (size_t)c * N) + ((unsigned)(C * M + S * NT) + tu);   // scalar base + lane offset
-                    char *dst = stage + (C * M + S * NT + (t & ~63)) * SZ;           // wave-uniform
+                    char *dst = stage + (C * M + S * NT + (t & ~63)) * TSZ;           // wave-uniform
                     auto gsrc = (const __attribute__((address_space(1))) void *)src;
                     auto ldst = (__attribute__((address_space(3))) void *)dst;
                     // the size operand must be a literal
-                    if constexpr (SZ == 4) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 0, 0);
-                    else if constexpr (SZ == 2) __builtin_amdgcn_global_load_lds(gsrc, ldst, 2, 0, 0);
+                    if constexpr (TSZ == 4) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 0, 0);
+                    else if constexpr (TSZ == 2) __builtin_amdgcn_global_load_lds(gsrc, ldst, 2, 0, 0);
                     else __builtin_amdgcn_global_load_lds(gsrc, ldst, 1, 0, 0);
                 });
             });
@@ -485,7 +493,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
             static_for<0, NTX>([&](auto C_) LDPC_INLINE {
                 constexpr int C = decltype(C_)::value;
-                if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * SZ));
+                if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * TSZ));
                 else llr[S][C] = live ? O::load((llrs + (size_t)cw * N)[(unsigned)(C * M + S * NT) + tu]) : O::zero();
             });
         });

@@ -103,7 +103,8 @@ def test_empty_batch():
     assert out.shape == (0, code.output_len()) and it.shape == (0,) and ok.shape == (0,)
 
 
-@pytest.mark.parametrize("code,variant", [(LDPCCode.TM8192, 2), (LDPCCode.TM2048, 2)], ids=["TM8192-ipt2", "TM2048-ipt2"])
+@pytest.mark.parametrize("code,variant", [(LDPCCode.TM8192, 4), (LDPCCode.TM2048, 2), (LDPCCode.TM1536, 2), (LDPCCode.TM6144, 2)],
+                         ids=["TM8192-ipt4", "TM2048-ipt2", "TM1536-ipt2", "TM6144-ipt2"])
 def test_variants(code, variant):
     rng = np.random.default_rng(21)
     llrs, _ = oracle.awgn_llrs(code, rng, 64, 2.0, np.float32)

@@ -17,6 +17,9 @@
 #ifndef KFRAMES
 #define KFRAMES 131072
 #endif
+#ifndef KT
+#define KT float
+#endif
 #ifndef KPF
 #define KPF false
 #endif
@@ -34,11 +37,11 @@ int main()
     const CodeInfo &ci = CODES[code];
     const size_t F = KFRAMES, n = ci.n, ol = ci.output_len();
     const float sigma = (float)std::sqrt(1.0 / (2.0 * ((double)ci.k / ci.n) * std::pow(10.0, KEBN0 / 10.0)));
-    uint8_t *pool; float *llrs; uint8_t *out, *ok; uint32_t *iters;
+    uint8_t *pool; KT *llrs; uint8_t *out, *ok; uint32_t *iters;
     CK(hipMalloc(&pool, n / 8)); CK(hipMemset(pool, 0, n / 8));
-    CK(hipMalloc(&llrs, F * n * 4)); CK(hipMalloc(&out, F * ol)); CK(hipMalloc(&ok, F)); CK(hipMalloc(&iters, F * 4));
-    CK(launch_awgn<float>(pool, 1, llrs, (int)n, F, sigma, 1.f, 0, 0x1DBCull + code, nullptr));
-    using GEO = Geometry<code, float, KIPT>;
+    CK(hipMalloc(&llrs, F * n * sizeof(KT))); CK(hipMalloc(&out, F * ol)); CK(hipMalloc(&ok, F)); CK(hipMalloc(&iters, F * 4));
+    CK(launch_awgn<KT>(pool, 1, llrs, (int)n, F, sigma, 8.f, 31, 0x1DBCull + code, nullptr));
+    using GEO = Geometry<code, KT, KIPT>;
     unsigned groups = (unsigned)((F + GEO::G - 1) / GEO::G);
 #ifdef KGRID
     if (groups > KGRID) groups = KGRID;          // persistent workgroups
@@ -47,7 +50,7 @@ int main()
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((decode_ms_kernel<code, float, KIPT, KPF>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
+        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep > 0 && ms < best) best = ms;
@@ -58,7 +61,7 @@ int main()
     double si = 0, sk = 0; unsigned long long h = 1469598103934665603ull;
     for (size_t f = 0; f < F; ++f) { si += hi[f]; sk += hk[f]; h = (h ^ hi[f] ^ ((unsigned long long)hk[f] << 32)) * 1099511628211ull; }
     for (size_t i = 0; i < F * ol; ++i) h = (h ^ ho[i]) * 1099511628211ull;
-    printf("code %d ipt %d pf %d grid %u frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", code, KIPT, (int)KPF, groups, F, best,
+    printf("code %d T%zu ipt %d pf %d grid %u frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", code, sizeof(KT), KIPT, (int)KPF, groups, F, best,
            F / best / 1e3, si / F, sk / F, h);
     return 0;
 }
