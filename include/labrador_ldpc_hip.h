@@ -135,6 +135,15 @@ int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code code, const int16_
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
 
+/* Batched systematic encoder on the GPU: codewords[f] = copy_encode(data[f]) for every frame
+ * (src/encoder.rs:293-315; the per-frame C entry is labrador_ldpc_copy_encode above).
+ *   data      [batch][k/8]   MSB-first bytes
+ *   codewords [batch][n/8]   first k/8 bytes = data, rest = parity
+ * Host or device buffers per opts->memory (device buffers 4-byte aligned); asynchronous with
+ * MEM_DEVICE.  Returns a status code. */
+int labrador_ldpc_encode_batch(enum labrador_ldpc_code code, const uint8_t *data, uint8_t *codewords,
+                               size_t batch, const struct labrador_ldpc_hip_opts *opts);
+
 /* Synthetic AWGN frames on the device (harness side of the path; what perftest's ms_trial does
  * per frame at perftest/src/main.rs:10-18, batched): frame f takes codeword (f mod pool) of
  * `codewords` ([pool][n/8] bytes, MSB first), maps bit b to 1-2b, adds sigma*N(0,1) from a

@@ -66,6 +66,7 @@ SYMBOLS = {
     "labrador_ldpc_decode_ms_batch_f32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i8": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i16": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_encode_batch": (_int, [_int, _vp, _vp, _sz, _optp]),
     "labrador_ldpc_hip_awgn_f32": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_uint64, _optp]),
     "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
                                          _c.c_uint64, _optp]),
@@ -301,6 +302,30 @@ class LDPCCode(enum.IntEnum):
         _check(fn(int(self), _ptr(llrs), _ptr(output), _ptr(iters), _ptr(success), batch, maxiters,
                   ctypes.byref(opts)))
         return output, iters, success
+
+    def encode_batch(self, data, codewords=None, stream: Optional[int] = None):
+        """Batched `copy_encode`: data[batch, k/8] -> codewords[batch, n/8] on the GPU.
+        numpy = host buffers (synchronous), torch CUDA uint8 tensors = device buffers (asynchronous)."""
+        if data.ndim != 2 or data.shape[1] != self.k() // 8:
+            raise ValueError("data must be [batch, k/8]")
+        batch = data.shape[0]
+        if _is_torch(data):
+            import torch
+            if not (data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()):
+                raise ValueError("data must be a contiguous uint8 CUDA tensor")
+            dev = data.device
+            if codewords is None:
+                codewords = torch.empty((batch, self.n() // 8), dtype=torch.uint8, device=dev)
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0)
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            if codewords is None:
+                codewords = np.empty((batch, self.n() // 8), dtype=np.uint8)
+            opts = HipOpts(-1, MEM_HOST, stream, 0)
+        _check(lib.labrador_ldpc_encode_batch(int(self), _ptr(data), _ptr(codewords), batch, ctypes.byref(opts)))
+        return codewords
 
     # ---- synthetic channel (harness) ----
     def awgn_frames(self, codewords, batch: int, sigma: float, seed: int, dtype="f32",

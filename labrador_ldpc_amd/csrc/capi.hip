@@ -13,6 +13,7 @@
 
 #include "../../include/labrador_ldpc_hip.h"
 #include "channel.hpp"
+#include "encode.hpp"
 #include "codes.hpp"
 #include "host_codes.hpp"
 
@@ -271,6 +272,37 @@ int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code c, const int16_t *
                                       const struct labrador_ldpc_hip_opts *opts)
 {
     return decode_batch<int16_t>(c, llrs, output, iters, success, batch, max_iters, opts);
+}
+
+// ---- batched encoder ------------------------------------------------------------------------------
+int labrador_ldpc_encode_batch(enum labrador_ldpc_code c, const uint8_t *data, uint8_t *codewords, size_t batch,
+                               const struct labrador_ldpc_hip_opts *opts)
+{
+    g_err.clear();
+    if (!ldpc::valid_code(c)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", (int)c);
+    if (batch == 0) return LABRADOR_LDPC_HIP_OK;
+    if (!data || !codewords) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
+    const size_t kb = ldpc::CODES[c].k / 8, nb = ldpc::CODES[c].n / 8;
+    hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+    DeviceScope scope;
+    if (int s = scope.enter(opts)) return s;
+    if (opts && opts->memory == LABRADOR_LDPC_HIP_MEM_DEVICE) {
+        if ((uintptr_t)data % 4 || (uintptr_t)codewords % 4)
+            return fail(LABRADOR_LDPC_HIP_EINVAL, "device buffers must be 4-byte aligned");
+        hipError_t e = ldpc::launch_encode(c, data, codewords, batch, stream);
+        if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "encode launch: %s", hipGetErrorString(e));
+        return LABRADOR_LDPC_HIP_OK;
+    }
+    if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
+    DeviceBuffer d_in, d_out;
+    HIP_TRY(d_in.alloc(batch * kb));
+    HIP_TRY(d_out.alloc(batch * nb));
+    HIP_TRY(hipMemcpyAsync(d_in.p, data, batch * kb, hipMemcpyHostToDevice, stream));
+    hipError_t e = ldpc::launch_encode(c, (const uint8_t *)d_in.p, (uint8_t *)d_out.p, batch, stream);
+    if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "encode launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(codewords, d_out.p, batch * nb, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return LABRADOR_LDPC_HIP_OK;
 }
 
 // ---- channel -------------------------------------------------------------------------------------
