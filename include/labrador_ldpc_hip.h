@@ -63,9 +63,9 @@ void labrador_ldpc_encode(enum labrador_ldpc_code code, uint8_t *codeword);
 void labrador_ldpc_copy_encode(enum labrador_ldpc_code code, const uint8_t *data, uint8_t *codeword);
 
 /* capi/include/labrador_ldpc.h:167-170  (capi/src/lib.rs:68-81; src/decoder.rs:243-301).
- * Bit-flipping decoder: outside this build's hot path.  The symbol
- * is exported so that existing callers link; it always returns false and sets the error
- * string to "decode_bf: not implemented". */
+ * Bit-flipping decoder (with the erasure pre-pass for punctured codes), one codeword, host
+ * pointers, on the GPU.  `input` n/8 bytes, `output` output_len bytes, `working` is accepted and
+ * not touched, `iters_run` may be NULL. */
 bool labrador_ldpc_decode_bf(enum labrador_ldpc_code code, const uint8_t *input, uint8_t *output,
                              uint8_t *working, size_t max_iters, size_t *iters_run);
 
@@ -134,6 +134,13 @@ int labrador_ldpc_decode_ms_batch_i8 (enum labrador_ldpc_code code, const int8_t
 int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output,
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
+
+/* Batched bit-flipping decoder (src/decoder.rs:243-301), the batched form of
+ * labrador_ldpc_decode_bf:  input [batch][n/8], output [batch][output_len], iters [batch]
+ * (bit-flipping iterations + erasure iterations, or that sum's maximum on failure), success [batch]. */
+int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code code, const uint8_t *input, uint8_t *output,
+                                  uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
+                                  const struct labrador_ldpc_hip_opts *opts);
 
 /* Batched systematic encoder on the GPU: codewords[f] = copy_encode(data[f]) for every frame
  * (src/encoder.rs:293-315; the per-frame C entry is labrador_ldpc_copy_encode above).

@@ -66,6 +66,7 @@ SYMBOLS = {
     "labrador_ldpc_decode_ms_batch_f32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i8": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i16": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_decode_bf_batch": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_encode_batch": (_int, [_int, _vp, _vp, _sz, _optp]),
     "labrador_ldpc_hip_awgn_f32": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_uint64, _optp]),
     "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
@@ -301,6 +302,48 @@ class LDPCCode(enum.IntEnum):
             opts = HipOpts(-1, MEM_HOST, stream, variant)
         _check(fn(int(self), _ptr(llrs), _ptr(output), _ptr(iters), _ptr(success), batch, maxiters,
                   ctypes.byref(opts)))
+        return output, iters, success
+
+    # ---- bit-flipping decoder: src/decoder.rs:243-301 ----
+    def decode_bf(self, input: np.ndarray, output: np.ndarray, working: Optional[np.ndarray] = None,
+                  maxiters: int = 50) -> Tuple[bool, int]:
+        """One codeword on the GPU; (success, iterations) like the crate (length checks of :247-249)."""
+        inp = _as_u8(input, self.n() // 8, "input.len() != n/8")
+        out = _as_u8(output, self.output_len(), "output.len != (n+p)/8")
+        if working is not None and working.shape != (self.decode_bf_working_len(),):
+            raise ValueError("working.len() incorrect")
+        iters = ctypes.c_size_t(0)
+        ok = lib.labrador_ldpc_decode_bf(int(self), inp.ctypes.data, out.ctypes.data, None, maxiters, ctypes.byref(iters))
+        err = last_error()
+        if not ok and err:
+            raise LdpcHipError(err)
+        return bool(ok), int(iters.value)
+
+    def decode_bf_batch(self, input, maxiters: int = 50, stream: Optional[int] = None):
+        """input[batch, n/8] -> (output[batch, output_len], iters[batch], success[batch]).
+        numpy = host buffers, torch CUDA uint8 tensors = device buffers (asynchronous)."""
+        if input.ndim != 2 or input.shape[1] != self.n() // 8:
+            raise ValueError("input must be [batch, n/8]")
+        batch = input.shape[0]
+        if _is_torch(input):
+            import torch
+            if not (input.is_cuda and input.dtype == torch.uint8 and input.is_contiguous()):
+                raise ValueError("input must be a contiguous uint8 CUDA tensor")
+            dev = input.device
+            output = torch.empty((batch, self.output_len()), dtype=torch.uint8, device=dev)
+            iters = torch.empty((batch,), dtype=torch.int32, device=dev)
+            success = torch.empty((batch,), dtype=torch.uint8, device=dev)
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0)
+        else:
+            input = np.ascontiguousarray(input, dtype=np.uint8)
+            output = np.empty((batch, self.output_len()), dtype=np.uint8)
+            iters = np.empty((batch,), dtype=np.uint32)
+            success = np.empty((batch,), dtype=np.uint8)
+            opts = HipOpts(-1, MEM_HOST, stream, 0)
+        _check(lib.labrador_ldpc_decode_bf_batch(int(self), _ptr(input), _ptr(output), _ptr(iters), _ptr(success),
+                                                 batch, maxiters, ctypes.byref(opts)))
         return output, iters, success
 
     def encode_batch(self, data, codewords=None, stream: Optional[int] = None):

@@ -14,6 +14,7 @@
 #include "../../include/labrador_ldpc_hip.h"
 #include "channel.hpp"
 #include "encode.hpp"
+#include "decode_bf.hpp"
 #include "codes.hpp"
 #include "host_codes.hpp"
 
@@ -214,11 +215,54 @@ void labrador_ldpc_copy_encode(enum labrador_ldpc_code c, const uint8_t *data, u
     ldpc::encode_parity(c, codeword, codeword + ldpc::CODES[c].k / 8);
 }
 
-// ---- bit-flipping decoder: out of this build's scope (capi/src/lib.rs:68-81) ------------------
-bool labrador_ldpc_decode_bf(enum labrador_ldpc_code, const uint8_t *, uint8_t *, uint8_t *, size_t, size_t *)
+// ---- bit-flipping decoder: capi/src/lib.rs:68-81 -----------------------------------------------
+int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code c, const uint8_t *input, uint8_t *output, uint32_t *iters,
+                                  uint8_t *success, size_t batch, size_t max_iters,
+                                  const struct labrador_ldpc_hip_opts *opts)
 {
-    fail(LABRADOR_LDPC_HIP_EUNSUPPORTED, "decode_bf: not implemented");
-    return false;
+    g_err.clear();
+    if (!ldpc::valid_code(c)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", (int)c);
+    if (batch == 0) return LABRADOR_LDPC_HIP_OK;
+    if (!input || !output || !iters || !success) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
+    const uint32_t maxit = max_iters > 0x7FFFFFFEull ? 0x7FFFFFFEu : (uint32_t)max_iters;
+    const size_t in_len = ldpc::CODES[c].n / 8, out_len = ldpc::CODES[c].output_len();
+    hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+    DeviceScope scope;
+    if (int s = scope.enter(opts)) return s;
+    if (opts && opts->memory == LABRADOR_LDPC_HIP_MEM_DEVICE) {
+        hipError_t e = ldpc::launch_decode_bf(c, input, output, iters, success, batch, maxit, stream);
+        if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "decode_bf launch: %s", hipGetErrorString(e));
+        return LABRADOR_LDPC_HIP_OK;
+    }
+    if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
+    DeviceBuffer d_in, d_out, d_it, d_ok;
+    HIP_TRY(d_in.alloc(batch * in_len));
+    HIP_TRY(d_out.alloc(batch * out_len));
+    HIP_TRY(d_it.alloc(batch * sizeof(uint32_t)));
+    HIP_TRY(d_ok.alloc(batch));
+    HIP_TRY(hipMemcpyAsync(d_in.p, input, batch * in_len, hipMemcpyHostToDevice, stream));
+    hipError_t e = ldpc::launch_decode_bf(c, (const uint8_t *)d_in.p, (uint8_t *)d_out.p, (uint32_t *)d_it.p,
+                                          (uint8_t *)d_ok.p, batch, maxit, stream);
+    if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "decode_bf launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(output, d_out.p, batch * out_len, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(iters, d_it.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(success, d_ok.p, batch, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return LABRADOR_LDPC_HIP_OK;
+}
+
+bool labrador_ldpc_decode_bf(enum labrador_ldpc_code c, const uint8_t *input, uint8_t *output, uint8_t *,
+                             size_t max_iters, size_t *iters_run)
+{
+    uint32_t it = 0;
+    uint8_t ok = 0;
+    const int s = labrador_ldpc_decode_bf_batch(c, input, output, &it, &ok, 1, max_iters, nullptr);
+    if (s != LABRADOR_LDPC_HIP_OK) {
+        std::fprintf(stderr, "labrador_ldpc_hip: decode_bf failed: %s\n", g_err.c_str());
+        return false;
+    }
+    if (iters_run) *iters_run = ok ? (size_t)it : max_iters;
+    return ok != 0;
 }
 
 // ---- min-sum decoder, one frame: capi/src/lib.rs:97-127 ---------------------------------------

@@ -17,6 +17,7 @@
  *   - decode_ms on clean punctured codewords         (src/decoder.rs:607-645)
  *   - hard_to_llrs / llrs_to_hard vectors            (src/decoder.rs:553-605)
  *   - working/output length tables                   (src/decoder.rs:531-551)
+ *   - decode_bf three-flip scenario, decode_erasures  (src/decoder.rs:607-670, src/lib.rs:21-50)
  * Iteration counts, non-converged outputs and noisy soft inputs are NOT
  * asserted by any reference test: for those the oracle is pinned only by its
  * fidelity to src/decoder.rs:347-475 (stated in DESIGN.md).
@@ -84,6 +85,12 @@ int oracle_decode_ms_batch_f32(int code, const float   *llrs, uint8_t *output, u
                                uint8_t *success, size_t batch, size_t maxiters, int nthreads);
 int oracle_decode_ms_batch_f64(int code, const double  *llrs, uint8_t *output, uint32_t *iters,
                                uint8_t *success, size_t batch, size_t maxiters, int nthreads);
+
+/* decode_bf (src/decoder.rs:243-301) and its erasure pre-pass decode_erasures (:144-223).
+ * `working` has bf_working_len bytes.  Return 1 / 0 (success), -1 bad code. */
+int oracle_decode_bf(int code, const uint8_t *input, uint8_t *output, uint8_t *working,
+                     size_t maxiters, size_t *iters_run);
+int oracle_decode_erasures(int code, uint8_t *codeword, uint8_t *working, size_t maxiters, size_t *iters_run);
 
 /* hard_to_llrs / llrs_to_hard (src/decoder.rs:484-509). */
 void oracle_hard_to_llrs_i8 (int code, const uint8_t *input, int8_t  *llrs);

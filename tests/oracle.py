@@ -37,6 +37,12 @@ def _load():
     L.oracle_syndrome_weight.argtypes = [ctypes.c_int, ctypes.c_void_p]
     L.oracle_encode.argtypes = [ctypes.c_int, ctypes.c_void_p]
     L.oracle_copy_encode.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.oracle_decode_bf.restype = ctypes.c_int
+    L.oracle_decode_bf.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_size_t)]
+    L.oracle_decode_erasures.restype = ctypes.c_int
+    L.oracle_decode_erasures.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_size_t)]
     for s in _SUF.values():
         fn = getattr(L, "oracle_decode_ms_" + s)
         fn.restype = ctypes.c_int
@@ -90,6 +96,29 @@ def decode_ms(code, llrs: np.ndarray, maxiters: int):
                                              w8.ctypes.data, maxiters, ctypes.byref(it))
     assert ok >= 0
     return bool(ok), int(it.value), out
+
+
+def decode_bf(code, hard: np.ndarray, maxiters: int):
+    """(success, iters, output) of the bit-flipping decoder on n/8 hard bytes."""
+    code = int(code)
+    hard = np.ascontiguousarray(hard, dtype=np.uint8)
+    assert hard.shape == (n(code) // 8,)
+    out = np.zeros(output_len(code), dtype=np.uint8)
+    w = np.zeros(L.oracle_bf_working_len(code), dtype=np.uint8)
+    it = ctypes.c_size_t(0)
+    ok = L.oracle_decode_bf(code, hard.ctypes.data, out.ctypes.data, w.ctypes.data, maxiters, ctypes.byref(it))
+    assert ok >= 0
+    return bool(ok), int(it.value), out
+
+
+def decode_erasures(code, codeword_np: np.ndarray, maxiters: int):
+    code = int(code)
+    cw = np.ascontiguousarray(codeword_np, dtype=np.uint8).copy()
+    assert cw.shape == (output_len(code),)
+    w = np.zeros(L.oracle_bf_working_len(code), dtype=np.uint8)
+    it = ctypes.c_size_t(0)
+    ok = L.oracle_decode_erasures(code, cw.ctypes.data, w.ctypes.data, maxiters, ctypes.byref(it))
+    return bool(ok), int(it.value), cw
 
 
 def decode_ms_batch(code, llrs: np.ndarray, maxiters: int, nthreads: int = 0):

@@ -100,3 +100,36 @@ def test_batch_driver_matches_single():
     for f in range(16):
         o1, i1, out1 = oracle.decode_ms(2, llrs[f], 25)
         assert (o1, i1) == (bool(ok[f]), int(iters[f])) and (out1 == out[f]).all()
+
+
+@pytest.mark.parametrize("code", CODES, ids=oracle.CODES)
+def test_decode_bf_three_flips(code, kats):
+    """src/decoder.rs:647-670: the bit-flipping decoder recovers three flipped bits within 50 iterations."""
+    cw = oracle.copy_encode(code, np.arange(oracle.k(code) // 8, dtype=np.uint8))
+    rx = cw.copy()
+    rx[0] ^= kats["decode_scenario"]["flip_byte0_mask"]
+    ok, iters, out = oracle.decode_bf(code, rx, 50)
+    assert ok and (out[: oracle.n(code) // 8] == cw).all()
+    assert oracle.syndrome_weight(code, out) == 0
+
+
+@pytest.mark.parametrize("code", [c for c in CODES if c >= 3], ids=oracle.CODES[3:])
+def test_decode_erasures_matches_min_sum(code):
+    """src/decoder.rs:607-645: on a clean codeword the erasure pre-pass succeeds and reconstructs the
+    punctured bits exactly as decode_ms does."""
+    cw = oracle.copy_encode(code, np.arange(oracle.k(code) // 8, dtype=np.uint8))
+    full = np.zeros(oracle.output_len(code), dtype=np.uint8)
+    full[: len(cw)] = cw
+    ok, iters, out = oracle.decode_erasures(code, full, 50)
+    ok_ms, _, out_ms = oracle.decode_ms(code, oracle.hard_to_llrs(code, cw, np.int8), 50)
+    assert ok and ok_ms and (out == out_ms).all()
+
+
+def test_decode_bf_doctest_round_trip():
+    """src/lib.rs:21-50: encode, flip one bit, decode_bf with 20 iterations recovers the data."""
+    code = 0                                              # TC128
+    cw = oracle.copy_encode(code, np.arange(oracle.k(code) // 8, dtype=np.uint8))
+    rx = cw.copy()
+    rx[0] ^= 1 << 7
+    ok, iters, out = oracle.decode_bf(code, rx, 20)
+    assert ok and (out[: oracle.k(code) // 8] == cw[: oracle.k(code) // 8]).all()
