@@ -79,10 +79,40 @@ struct DeviceScope {
     ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 
-struct DeviceBuffer {
+// Staging memory for the host-pointer entry points.  Each calling thread keeps a small set of
+// grow-only device buffers per device, so the reference-shaped single-frame calls do not pay a
+// hipMalloc/hipFree pair per frame (they are freed when the thread exits).
+struct StagingPool {
+    struct Slot { void *p = nullptr; size_t cap = 0; int dev = -1; };
+    Slot slots[8];
+    ~StagingPool() { for (auto &s : slots) if (s.p) (void)hipFree(s.p); }
+    hipError_t get(int idx, size_t bytes, void **out)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        Slot &s = slots[idx];
+        if (s.p && (s.dev != dev || s.cap < bytes)) {
+            (void)hipFree(s.p);                       // implicit sync: no work of ours still uses it (calls are synchronous)
+            s.p = nullptr; s.cap = 0;
+        }
+        if (!s.p) {
+            const size_t cap = bytes < 4096 ? 4096 : bytes;
+            e = hipMalloc(&s.p, cap);
+            if (e != hipSuccess) { s.p = nullptr; return e; }
+            s.cap = cap; s.dev = dev;
+        }
+        *out = s.p;
+        return hipSuccess;
+    }
+};
+thread_local StagingPool g_pool;
+
+struct DeviceBuffer {                                 // a view into the calling thread's staging pool
     void *p = nullptr;
-    ~DeviceBuffer() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    int idx;
+    explicit DeviceBuffer(int slot) : idx(slot) {}
+    hipError_t alloc(size_t bytes) { return g_pool.get(idx, bytes, &p); }
 };
 
 template <class T>
@@ -115,7 +145,7 @@ int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint
     // host buffers: stage in chunks so that arbitrarily large batches fit
     const size_t chunk_max = (size_t)1 << 16;
     const size_t chunk = batch < chunk_max ? batch : chunk_max;
-    DeviceBuffer d_llr, d_out, d_it, d_ok;
+    DeviceBuffer d_llr(0), d_out(1), d_it(2), d_ok(3);
     HIP_TRY(d_llr.alloc(chunk * n * sizeof(T)));
     HIP_TRY(d_out.alloc(chunk * out_len));
     HIP_TRY(d_it.alloc(chunk * sizeof(uint32_t)));
@@ -235,7 +265,7 @@ int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code c, const uint8_t *inpu
         return LABRADOR_LDPC_HIP_OK;
     }
     if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
-    DeviceBuffer d_in, d_out, d_it, d_ok;
+    DeviceBuffer d_in(0), d_out(1), d_it(2), d_ok(3);
     HIP_TRY(d_in.alloc(batch * in_len));
     HIP_TRY(d_out.alloc(batch * out_len));
     HIP_TRY(d_it.alloc(batch * sizeof(uint32_t)));
@@ -338,7 +368,7 @@ int labrador_ldpc_encode_batch(enum labrador_ldpc_code c, const uint8_t *data, u
         return LABRADOR_LDPC_HIP_OK;
     }
     if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
-    DeviceBuffer d_in, d_out;
+    DeviceBuffer d_in(0), d_out(1);
     HIP_TRY(d_in.alloc(batch * kb));
     HIP_TRY(d_out.alloc(batch * nb));
     HIP_TRY(hipMemcpyAsync(d_in.p, data, batch * kb, hipMemcpyHostToDevice, stream));
