@@ -49,6 +49,12 @@
 // for LDS operations only and not for the asynchronous LLR staging copies counted in vmcnt.
 #define LDPC_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+// Experiment switch: split (arrive / wait) barrier between the variable and the check phase.
+// Measured SLOWER on TM8192 (5.09 vs 5.34 M codewords/s): with it the exchanged marginals can only be
+// requested after the wait, so their latency is no longer covered by the local-edge work.  Off.
+#ifndef LDPC_SPLIT_BARRIER
+#define LDPC_SPLIT_BARRIER 0
+#endif
 #ifdef LDPC_DIAG_FIXED_ITERS
 #define LDPC_DIAG_EARLY_EXIT 0
 #else
@@ -399,6 +405,27 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
 
+    // Split barrier between the variable and the check phase (single-codeword workgroups): a
+    // wave ARRIVES (LDS counter) as soon as its marginals are stored, updates its local edges,
+    // and only then WAITS for the other waves -- the arrival skew that a plain s_barrier turns
+    // into idle time is spent on work that needs no exchanged data.  LDS operations of a wave
+    // execute in order, so the counter add needs no wait for the stores before it.
+    constexpr bool SPLIT = LDPC_SPLIT_BARRIER && G == 1 && NT >= 128;
+    constexpr int NWAVES = NT / 64 > 0 ? NT / 64 : 1;
+    const int cnt_addr = (int)(size_t)(__attribute__((address_space(3))) char *)(gbase + FLAG_OFF + 8);
+    auto arrive = [&]() LDPC_INLINE {
+        if ((tid & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_addr), "v"(1) : "memory");
+        else asm volatile("" ::: "memory");
+    };
+    auto wait_arrivals = [&](uint32_t expected) LDPC_INLINE {
+        for (;;) {
+            uint32_t c;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(cnt_addr) : "memory");
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)c) >= expected) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
     // Byte offset, inside one block's M*SZ-byte LDS region, of the variable that check
     // i = S*NT + t of block B is wired to; `tb` is t*SZ.  Identity blocks rotate the whole
     // region, pi_k blocks move quarter j to quarter (theta_k + j) mod 4 and rotate inside it
@@ -498,6 +525,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
             });
         });
         if (t < 2) flag_at(t) = 0;
+        if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;      // split-barrier arrival counter
     };
 
     // One iteration of message passing for this thread's indices: the two phases below.
@@ -531,6 +559,23 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         });
     };
 
+    auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
+        constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+        const R nv = O::sub(x, u[S][B]);                                               // :421
+        // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
+        const R nw = O::select_zero(O::drop(nv, v[S][B]), nv);
+        v[S][B] = nw;
+    };
+    // the part of the check update that needs no exchanged data: the LOCAL edges
+    auto check_local = [&]() LDPC_INLINE {
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col]);
+            });
+        });
+    };
+
     auto check_phase = [&](uint32_t it) LDPC_INLINE {
         // decoder.rs:414-450, and :391-405 of the NEXT iteration
         int par_any = 0;          // bit 31 set if any owned check has odd parity
@@ -558,20 +603,10 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
             });
         });
         __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
-        auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
-            constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-            const R nv = O::sub(x, u[S][B]);                                           // :421
-            // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
-            const R nw = O::select_zero(O::drop(nv, v[S][B]), nv);
-            v[S][B] = nw;
-        };
-        static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2)
-            static_for<0, NB>([&](auto B_) LDPC_INLINE {
-                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col]);
-            });
-        });
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!SPLIT) {
+            check_local();                                                             // (2)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
@@ -638,7 +673,13 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         else { if (__all(done)) break; }
 
         if (G == 1 || !done) variable_phase();
-        LDPC_SYNC();
+        if constexpr (SPLIT) {
+            arrive();
+            check_local();
+            wait_arrivals((uint32_t)NWAVES * (it + 1));
+        } else {
+            LDPC_SYNC();
+        }
         if (it > 0 && t == 0) flag_at(it - 1) = 0;
         if (G == 1 || !done) check_phase(it);
     }
