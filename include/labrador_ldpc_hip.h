@@ -70,7 +70,8 @@ bool labrador_ldpc_decode_bf(enum labrador_ldpc_code code, const uint8_t *input,
                              uint8_t *working, size_t max_iters, size_t *iters_run);
 
 /* capi/include/labrador_ldpc.h:193-208  (capi/src/lib.rs:83-127; src/decoder.rs:347-475).
- * One codeword, host pointers; runs the same kernel as the batched calls with batch = 1.
+ * One codeword, host pointers; runs the same kernels as the batched calls with batch = 1
+ * (f64: a general, slower kernel, see labrador_ldpc_decode_ms_batch_f64).
  * `llrs` n entries, `output` output_len bytes, `iters_run` may be NULL. */
 bool labrador_ldpc_decode_ms_i8 (enum labrador_ldpc_code code, const int8_t  *llrs, uint8_t *output,
                                  int8_t  *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
@@ -132,6 +133,11 @@ int labrador_ldpc_decode_ms_batch_i8 (enum labrador_ldpc_code code, const int8_t
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
 int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output,
+                                      uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts);
+/* f64: same results contract; a general (untuned) kernel that keeps the per-edge messages in a
+ * device workspace allocated per call -- see DESIGN.md. */
+int labrador_ldpc_decode_ms_batch_f64(enum labrador_ldpc_code code, const double *llrs, uint8_t *output,
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
 

@@ -66,6 +66,7 @@ SYMBOLS = {
     "labrador_ldpc_decode_ms_batch_f32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i8": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i16": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_decode_ms_batch_f64": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_bf_batch": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_encode_batch": (_int, [_int, _vp, _vp, _sz, _optp]),
     "labrador_ldpc_hip_awgn_f32": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_uint64, _optp]),

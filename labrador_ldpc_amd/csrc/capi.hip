@@ -311,11 +311,10 @@ bool labrador_ldpc_decode_ms_f32(enum labrador_ldpc_code c, const float *llrs, u
 {
     return decode_one<float>(c, llrs, output, max_iters, iters_run);
 }
-bool labrador_ldpc_decode_ms_f64(enum labrador_ldpc_code, const double *, uint8_t *, double *, uint8_t *, size_t, size_t *)
+bool labrador_ldpc_decode_ms_f64(enum labrador_ldpc_code c, const double *llrs, uint8_t *output, double *, uint8_t *,
+                                 size_t max_iters, size_t *iters_run)
 {
-    fail(LABRADOR_LDPC_HIP_EUNSUPPORTED, "decode_ms_f64: no GPU kernel in this build");
-    std::fprintf(stderr, "labrador_ldpc_hip: decode_ms_f64: no GPU kernel in this build\n");
-    return false;
+    return decode_one<double>(c, llrs, output, max_iters, iters_run);
 }
 
 // ---- LLR helpers: capi/src/lib.rs:129-179 ------------------------------------------------------
@@ -377,6 +376,13 @@ int labrador_ldpc_encode_batch(enum labrador_ldpc_code c, const uint8_t *data, u
     HIP_TRY(hipMemcpyAsync(codewords, d_out.p, batch * nb, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return LABRADOR_LDPC_HIP_OK;
+}
+
+int labrador_ldpc_decode_ms_batch_f64(enum labrador_ldpc_code c, const double *llrs, uint8_t *output, uint32_t *iters,
+                                      uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts)
+{
+    return decode_batch<double>(c, llrs, output, iters, success, batch, max_iters, opts);
 }
 
 // ---- channel -------------------------------------------------------------------------------------

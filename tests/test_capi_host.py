@@ -110,11 +110,3 @@ def test_decode_without_gpu_fails_loudly():
         code.decode_bf(np.zeros(code.n() // 8, dtype=np.uint8), np.zeros(code.output_len(), dtype=np.uint8))
     with pytest.raises(la.LdpcHipError):
         code.encode_batch(np.zeros((2, code.k() // 8), dtype=np.uint8))
-
-
-def test_f64_entry_point_says_unsupported():
-    code = LDPCCode.TC128
-    out = np.zeros(code.output_len(), dtype=np.uint8)
-    llrs = np.zeros(code.n(), dtype=np.float64)
-    assert not la.lib.labrador_ldpc_decode_ms_f64(0, llrs.ctypes.data, out.ctypes.data, None, None, 10, None)
-    assert "no GPU kernel" in la.last_error()

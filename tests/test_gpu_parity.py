@@ -23,7 +23,7 @@ def _compare(code, llrs, maxiters, variant=0):
 
 
 @pytest.mark.parametrize("code", ALL, ids=lambda c: c.name)
-@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16], ids=["f32", "i8", "i16"])
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16, np.float64], ids=["f32", "i8", "i16", "f64"])
 def test_three_flip_scenario(code, dtype):
     """test_decode_ms of the reference (src/decoder.rs:671-699): 3 flipped bits, +-1 LLRs, 50 iters."""
     cw = oracle.copy_encode(code, np.arange(code.k() // 8, dtype=np.uint8))
@@ -39,7 +39,7 @@ def test_three_flip_scenario(code, dtype):
 
 
 @pytest.mark.parametrize("code", ALL, ids=lambda c: c.name)
-@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16], ids=["f32", "i8", "i16"])
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16, np.float64], ids=["f32", "i8", "i16", "f64"])
 def test_awgn_parity(code, dtype):
     """Seeded AWGN frames across the waterfall: early/late convergence and failures."""
     rng = np.random.default_rng(0x1DBC + int(code))
@@ -109,3 +109,18 @@ def test_variants(code, variant):
     rng = np.random.default_rng(21)
     llrs, _ = oracle.awgn_llrs(code, rng, 64, 2.0, np.float32)
     _compare(code, llrs, 25, variant=variant)
+
+
+@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TM1280, LDPCCode.TM8192], ids=lambda c: c.name)
+def test_f64_corner_values(code):
+    """f64 path with signed zeros, denormals, infinities (real comparisons as in src/decoder.rs:78-86)."""
+    rng = np.random.default_rng(31 + int(code))
+    llrs, _ = oracle.awgn_llrs(code, rng, 32, 3.0, np.float64)
+    llrs[0, :] = 0.0
+    llrs[1, :] = -0.0
+    llrs[2, ::3] = -0.0
+    llrs[3] *= 1e-310
+    llrs[4] *= 1e307
+    llrs[5, ::7] = np.inf
+    llrs[6, ::11] = -np.inf
+    _compare(code, llrs, 20)
