@@ -55,6 +55,11 @@
 #ifndef LDPC_SPLIT_BARRIER
 #define LDPC_SPLIT_BARRIER 0
 #endif
+// Experiment switch: zero the dropped lanes by EXEC predication (v_cmpx + v_mov) instead of
+// v_cndmask.  Measured SLOWER on TM8192 (4.35 vs 5.34 M codewords/s: EXEC writes stall the VALU). Off.
+#ifndef LDPC_CMPX_SELECT
+#define LDPC_CMPX_SELECT 0
+#endif
 #ifdef LDPC_DIAG_FIXED_ITERS
 #define LDPC_DIAG_EARLY_EXIT 0
 #else
@@ -212,6 +217,22 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     {
         const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
         return __int_as_float(t) < 0.0f;
+    }
+    // nv, or +0 where drop(nv, old).  With all lanes active (FULL_EXEC) the select is done by
+    // predication -- v_cmpx writes EXEC, a v_mov zeroes the dropped lanes, EXEC is restored --
+    // because v_mov issues at the fast VALU rate and v_cndmask does not (tools/ubench).
+    template <bool FULL_EXEC>
+    LDPC_DEV static R self_correct(R nv, R old)
+    {
+#if LDPC_CMPX_SELECT
+        if constexpr (FULL_EXEC) {
+            const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
+            R nw = nv;
+            asm("v_cmpx_gt_f32_e32 vcc, 0, %1\n\tv_mov_b32_e32 %0, 0\n\ts_mov_b64 exec, -1" : "+v"(nw) : "v"(t) : "vcc");
+            return nw;
+        }
+#endif
+        return select_zero(drop(nv, old), nv);
     }
     // m >= 0 has bit 31 clear, so "m with sign s_all ^ s_own" is one three-input XOR of sign words
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
@@ -563,7 +584,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         const R nv = O::sub(x, u[S][B]);                                               // :421
         // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
-        const R nw = O::select_zero(O::drop(nv, v[S][B]), nv);
+        const R nw = O::template self_correct<G == 1>(nv, v[S][B]);
         v[S][B] = nw;
     };
     // the part of the check update that needs no exchanged data: the LOCAL edges
