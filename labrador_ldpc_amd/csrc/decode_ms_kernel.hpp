@@ -60,6 +60,9 @@
 #ifndef LDPC_CMPX_SELECT
 #define LDPC_CMPX_SELECT 0
 #endif
+#ifndef LDPC_QUARTER_SPECIALISE
+#define LDPC_QUARTER_SPECIALISE 2
+#endif
 #ifdef LDPC_DIAG_FIXED_ITERS
 #define LDPC_DIAG_EARLY_EXIT 0
 #else
@@ -370,13 +373,13 @@ LDPC_DEV int pi_dev(int i, int j)
     return (((TH + j) & 3) << LQ) + ((phi + i) & (Q - 1));
 }
 
-// PF: stage the NEXT codeword's LLRs in LDS with asynchronous global->LDS loads while the current
-// one is being decoded (costs n*sizeof(T) bytes of LDS; used where one workgroup fills the CU).
-template <int CODE, class T, int IPT, bool PF>
-__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG))
-decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
-                 uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                 uint32_t batch, uint32_t maxiters)
+// JW >= 0: the body is specialised for waves whose indices start in quarter JW (the kernel
+// branches once, wave-uniformly, into the matching copy) so that every rotation constant of the
+// pi_k blocks is a literal; JW < 0: generic body, constants in SGPRs.
+template <int CODE, class T, int IPT, bool PF, int JW>
+LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
+                             uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
+                             uint32_t batch, uint32_t maxiters, char *lds, char *stage)
 {
     using GEO = Geometry<CODE, T, IPT>;
     using O = Ops<T>;
@@ -402,8 +405,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     static_assert(!PF || (G == 1 && NT >= 64), "LLR staging needs whole waves per codeword");
     constexpr int TSZ = sizeof(T);
     constexpr int STAGE_BYTES = PF ? N * TSZ : 0;
-    __shared__ __attribute__((aligned(16))) char lds[G * GROUP_BYTES];
-    __shared__ __attribute__((aligned(16))) char stage[PF ? STAGE_BYTES : 16];   // own object: see stage_issue()
+    (void)STAGE_BYTES;
 
     const int tid = threadIdx.x;
     const int grp = G == 1 ? 0 : tid / NT;
@@ -452,7 +454,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // region, pi_k blocks move quarter j to quarter (theta_k + j) mod 4 and rotate inside it
     // (compact_parity_checks.rs:107-108).  Two VALU operations: add, and-or.
     constexpr int Q = M / 4, LQ = ilog2(Q);
-    constexpr bool QUARTER_LITERAL = NT <= Q;            // a thread's index S never leaves a quarter
+    constexpr bool QUARTER_LITERAL = NT <= Q || JW >= 0; // the quarter of index S is a literal
     constexpr bool QUARTER_SCALAR = !QUARTER_LITERAL && Q >= 64;   // a wave never straddles quarters
     int rot_s[IPT][NB], base_s[IPT][NB];                 // wave-uniform (SGPR) constants, QUARTER_SCALAR only
     if constexpr (QUARTER_SCALAR) {
@@ -479,7 +481,7 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
         if constexpr (blk.kind == BLK_I) {
             return ((tb + (S * NT + blk.val) * SZ) & (M * SZ - 1)) | bias;
         } else if constexpr (QUARTER_LITERAL) {
-            constexpr int j = (S * NT) / Q, K = blk.val;
+            constexpr int j = JW >= 0 ? S * (NT / Q) + JW : (S * NT) / Q, K = blk.val;
             return ((tb + (phi_of(K, j, M) + S * NT) * SZ) & (Q * SZ - 1)) | ((((theta_of(K) + j) & 3) << LQ) * SZ + bias);
         } else if constexpr (QUARTER_SCALAR) {
             return ((tb + rot_s[S][B]) & (Q * SZ - 1)) | base_s[S][B];
@@ -740,6 +742,40 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
     LDPC_SYNC();                  // every wave is done with the flags before the next codeword resets them
     }                             // persistent loop over codeword groups
+}
+
+
+// PF: stage the NEXT codeword's LLRs in LDS with asynchronous global->LDS loads while the current
+// one is being decoded (costs n*sizeof(T) bytes of LDS).
+template <int CODE, class T, int IPT, bool PF>
+__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG))
+decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
+                 uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
+                 uint32_t batch, uint32_t maxiters)
+{
+    using GEO = Geometry<CODE, T, IPT>;
+    constexpr int Q = GEO::M / 4;
+    constexpr int GROUP_BYTES = ((GEO::NX + GEO::NXC) * GEO::M * (int)sizeof(typename Ops<T>::E) + 8 + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) char lds[GEO::G * GROUP_BYTES];
+    __shared__ __attribute__((aligned(16))) char stage[PF ? CODES[CODE].n * sizeof(T) : 16];
+    // Waves of a workgroup whose threads own two quarters' worth of indices (TM8192: 1024 threads,
+    // quarters of 512) differ only in which quarter they start in: one wave-uniform branch
+    // selects a body with all pi_k constants folded (the barriers inside both copies count
+    // arrivals of the whole workgroup, whichever copy a wave runs).
+    if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
+            decode_ms_body<CODE, T, IPT, PF, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else
+            decode_ms_body<CODE, T, IPT, PF, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+    } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
+        const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, 2>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, 3>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+    } else {
+        decode_ms_body<CODE, T, IPT, PF, -1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+    }
 }
 
 
