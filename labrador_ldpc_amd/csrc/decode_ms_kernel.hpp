@@ -63,6 +63,13 @@
 #ifndef LDPC_QUARTER_SPECIALISE
 #define LDPC_QUARTER_SPECIALISE 2
 #endif
+// Experiment switch: issue the next codeword's LLR loads before the current one's epilogue.  Lowers the
+// fixed cost per codeword (1.66 -> 1.26 ms per 131 072 frames at 0 iterations) but the full decode got
+// 1.5 % SLOWER on TM8192 (5.50 vs 5.59 M codewords/s, twice, same process): register allocation of the
+// main loop changes.  Off.
+#ifndef LDPC_EARLY_FETCH
+#define LDPC_EARLY_FETCH 0
+#endif
 #ifdef LDPC_DIAG_FIXED_ITERS
 #define LDPC_DIAG_EARLY_EXIT 0
 #else
@@ -520,6 +527,22 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
+    // Plain global loads of codeword `c`'s LLRs into registers.  Issued BEFORE the previous
+    // codeword's hard-decision epilogue and this one's state initialisation, whose ~200
+    // instructions cover the HBM latency; the registers are the ones `llr` vacates when a decode ends.
+    T lraw[IPT][NTX];
+    auto fetch_llrs = [&](uint32_t c) LDPC_INLINE {
+        unsigned tu = (unsigned)t;
+        asm volatile("" : "+v"(tu));
+        const uint32_t cc = c < batch ? c : batch - 1;          // padding lanes of a last, partial group
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
+                lraw[S][C] = (llrs + (size_t)cc * N)[(unsigned)(C * M + S * NT) + tu];
+            });
+        });
+    };
+
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
         if constexpr (PF) {
             if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,9 +567,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             static_for<0, NTX>([&](auto C_) LDPC_INLINE {
                 constexpr int C = decltype(C_)::value;
                 if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * TSZ));
-                else llr[S][C] = live ? O::load((llrs + (size_t)cw * N)[(unsigned)(C * M + S * NT) + tu]) : O::zero();
+                else llr[S][C] = O::load(lraw[S][C]);     // fetched by fetch_llrs() a whole epilogue earlier
             });
         });
+        (void)tu;
         if (t < 2) flag_at(t) = 0;
         if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;      // split-barrier arrival counter
     };
@@ -670,9 +694,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (par_any < 0) flag_at(it) = 1;
     };
 
+    if (blockIdx.x < n_groups) fetch_llrs(G == 1 ? blockIdx.x : blockIdx.x * G + grp);
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
     live = cw < batch;
+    if constexpr (!LDPC_EARLY_FETCH) { if (!first) fetch_llrs(cw); }
     begin_codeword(!first);
     if constexpr (PF) {
         // the staged LLRs are in registers (the loads above were waited for by their use in
@@ -705,6 +731,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
         if (it > 0 && t == 0) flag_at(it - 1) = 0;
         if (G == 1 || !done) check_phase(it);
+    }
+
+    if constexpr (!PF && LDPC_EARLY_FETCH) {
+        const uint32_t gn = g + gridDim.x;                   // next codeword of this workgroup, if any
+        if (gn < n_groups) fetch_llrs(G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gn) : gn * G + grp);
     }
 
     // ---- hard decision of the marginals, MSB first (decoder.rs:455-461 / :467-473) ------------
