@@ -610,7 +610,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         const R nv = O::sub(x, u[S][B]);                                               // :421
         // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
+#ifdef LDPC_DIAG_NOSELFCORR
+        const R nw = nv;
+#else
         const R nw = O::template self_correct<G == 1>(nv, v[S][B]);
+#endif
         v[S][B] = nw;
     };
     // the part of the check update that needs no exchanged data: the LOCAL edges
@@ -676,7 +680,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
                 const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
+#ifdef LDPC_DIAG_NOMIN
+                static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = O::mag(a[decltype(J_)::value]); });
+#else
                 exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
+#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
