@@ -383,7 +383,7 @@ LDPC_DEV int pi_dev(int i, int j)
 // JW >= 0: the body is specialised for waves whose indices start in quarter JW (the kernel
 // branches once, wave-uniformly, into the matching copy) so that every rotation constant of the
 // pi_k blocks is a literal; JW < 0: generic body, constants in SGPRs.
-template <int CODE, class T, int IPT, bool PF, int JW>
+template <int CODE, class T, int IPT, bool PF, bool LEAN, int JW>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                              uint32_t batch, uint32_t maxiters, char *lds, char *stage)
@@ -532,6 +532,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // instructions cover the HBM latency; the registers are the ones `llr` vacates when a decode ends.
     T lraw[IPT][NTX];
     auto fetch_llrs = [&](uint32_t c) LDPC_INLINE {
+        if constexpr (LEAN) return;
         unsigned tu = (unsigned)t;
         asm volatile("" : "+v"(tu));
         const uint32_t cc = c < batch ? c : batch - 1;          // padding lanes of a last, partial group
@@ -567,7 +568,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             static_for<0, NTX>([&](auto C_) LDPC_INLINE {
                 constexpr int C = decltype(C_)::value;
                 if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * TSZ));
-                else llr[S][C] = O::load(lraw[S][C]);     // fetched by fetch_llrs() a whole epilogue earlier
+                else if constexpr (!LEAN) llr[S][C] = O::load(lraw[S][C]);     // fetched by fetch_llrs()
             });
         });
         (void)tu;
@@ -584,7 +585,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
                 constexpr int C = decltype(C_)::value;
                 R acc = O::zero();
-                if constexpr (C < NTX) acc = llr[S][C];
+                if constexpr (C < NTX) {
+                    if constexpr (LEAN) acc = O::load((llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(C * M) + (unsigned)i]);
+                    else acc = llr[S][C];
+                }
                 static_for<0, NB>([&](auto B_) LDPC_INLINE {
                     constexpr int B = decltype(B_)::value;
                     if constexpr (P.blk[B].col == C) {
@@ -606,9 +610,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
     };
 
-    auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
+    auto edge_update = [&](auto S_, auto B_, R x, R uu) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-        const R nv = O::sub(x, u[S][B]);                                               // :421
+        const R nv = O::sub(x, uu);                                                    // :421
         // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
 #ifdef LDPC_DIAG_NOSELFCORR
         const R nw = nv;
@@ -622,7 +626,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col]);
+                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col], u[S][B]);
             });
         });
     };
@@ -661,7 +665,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B]);
+                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], u[S][B]);
             });
         });
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (4)
@@ -694,6 +698,71 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     if constexpr (slot >= 0) {
                         constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                         lds_store(off + ad[S][B], O::store(un));
+                    }
+                });
+                par_any |= par;
+            });
+        });
+        if (par_any < 0) flag_at(it) = 1;
+    };
+
+    // Register-lean check phase (LEAN): one check row at a time, its edges in chunks of six; the u
+    // of an exchanged edge is read back from the LDS slot it was stored to, nothing per edge but v
+    // (and the u of local edges) stays live between chunks; addresses are recomputed for the store.
+    auto check_phase_lean = [&](uint32_t it) LDPC_INLINE {
+        int par_any = 0;
+        int tb = t * SZ;
+        asm volatile("" : "+v"(tb));
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value;
+            static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
+                constexpr int Rw = decltype(R_)::value;
+                constexpr int D = row_degree(P, Rw);
+                constexpr int CH = 6, NCH = (D + CH - 1) / CH;
+                int par = 0, sgn = 0;
+                static_for<0, NCH>([&](auto K_) LDPC_INLINE {
+                    constexpr int J0 = decltype(K_)::value * CH, J1 = J0 + CH < D ? J0 + CH : D;
+                    R xr[CH], ur[CH];
+                    static_for<J0, J1>([&](auto J_) LDPC_INLINE {                      // requests
+                        constexpr int J = decltype(J_)::value;
+                        constexpr int B = row_block(P, Rw, J);
+                        constexpr int slot = exch_slot(P, B);
+                        if constexpr (slot >= 0) {
+                            constexpr int cs = col_slot(P, P.blk[B].col);
+                            constexpr int offx = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                            constexpr int offu = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                            const int adr = wire(IC<B>{}, S_, tb);
+                            xr[J - J0] = O::from_lds(lds_load(offx + adr));
+                            ur[J - J0] = O::from_lds(lds_load(offu + adr));
+                        } else {
+                            xr[J - J0] = va[S][P.blk[B].col];
+                            ur[J - J0] = u[S][B];
+                        }
+                    });
+                    static_for<J0, J1>([&](auto J_) LDPC_INLINE {
+                        constexpr int J = decltype(J_)::value;
+                        constexpr int B = row_block(P, Rw, J);
+                        edge_update(S_, IC<B>{}, xr[J - J0], ur[J - J0]);              // :421-425
+                        par ^= O::bits(xr[J - J0]);                                    // :445-447
+                        sgn ^= O::bits(v[S][B]) & (int)0x80000000;                     // :439-441
+                    });
+                });
+                R a[D], e[D];
+                static_for<0, D>([&](auto J_) LDPC_INLINE {
+                    constexpr int J = decltype(J_)::value, B = row_block(P, Rw, J);
+                    a[J] = v[S][B];
+                });
+                exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
+                static_for<0, D>([&](auto J_) LDPC_INLINE {
+                    constexpr int J = decltype(J_)::value;
+                    constexpr int B = row_block(P, Rw, J);
+                    const R un = O::apply_sign(e[J], sgn, O::bits(v[S][B]) & (int)0x80000000);   // :398-405
+                    constexpr int slot = exch_slot(P, B);
+                    if constexpr (slot >= 0) {
+                        constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                        lds_store(off + wire(IC<B>{}, S_, tb), O::store(un));
+                    } else {
+                        u[S][B] = un;
                     }
                 });
                 par_any |= par;
@@ -738,7 +807,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             LDPC_SYNC();
         }
         if (it > 0 && t == 0) flag_at(it - 1) = 0;
-        if (G == 1 || !done) check_phase(it);
+        if (G == 1 || !done) { if constexpr (LEAN) check_phase_lean(it); else check_phase(it); }
     }
 
     if constexpr (!PF && LDPC_EARLY_FETCH) {
@@ -786,8 +855,12 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 
 // PF: stage the NEXT codeword's LLRs in LDS with asynchronous global->LDS loads while the current
 // one is being decoded (costs n*sizeof(T) bytes of LDS).
-template <int CODE, class T, int IPT, bool PF>
-__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG))
+// LEAN: register-lean variant for the high-degree rate-4/5 codes (39 edges per index): the u of
+// the exchanged edges is re-read from LDS in the check phase instead of being kept in VGPRs and
+// the LLRs are re-read from global memory (L2) every iteration; this brings TM5120 under 128
+// VGPRs so that two workgroups share a CU.
+template <int CODE, class T, int IPT, bool PF, bool LEAN>
+__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (LEAN ? 4 : 1))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                  uint32_t batch, uint32_t maxiters)
@@ -803,17 +876,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // arrivals of the whole workgroup, whichever copy a wave runs).
     if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
-            decode_ms_body<CODE, T, IPT, PF, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
         else
-            decode_ms_body<CODE, T, IPT, PF, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
     } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
         const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
-        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
-        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
-        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, 2>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
-        else decode_ms_body<CODE, T, IPT, PF, 3>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
     } else {
-        decode_ms_body<CODE, T, IPT, PF, -1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
     }
 }
 

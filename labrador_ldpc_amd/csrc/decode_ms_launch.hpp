@@ -19,7 +19,7 @@ hipError_t launch_decode_ms(int code, int variant, const T *llrs, uint8_t *outpu
                             uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
 
 // Resident workgroups per device for one instantiation (occupancy x compute units), cached.
-template <int CODE, class T, int IPT, bool PF>
+template <int CODE, class T, int IPT, bool PF, bool LEAN>
 int resident_workgroups()
 {
     using GEO = Geometry<CODE, T, IPT>;
@@ -28,7 +28,7 @@ int resident_workgroups()
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (cached[dev] == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF>, GEO::WG, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF, LEAN>, GEO::WG, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         cached[dev] = per_cu * cus;
@@ -45,6 +45,10 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // codeword on TM8192 (4.99 vs 5.29 M codewords/s: the extra live state costs spills at the
     // 128-VGPR budget), so it stays off; see DESIGN.md section 7.
     constexpr bool PF = false;
+    // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
+    // is TM5120 only (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB).  Measured slower
+    // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
+    constexpr bool LEAN = CODE == TM5120 && IPT == 1;
     if (batch == 0) return hipSuccess;
     const size_t groups = (batch + GEO::G - 1) / GEO::G;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
@@ -53,10 +57,10 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // hundreds of codewords and the data-dependent iteration counts average out.  Where several
     // fit per CU the grid is 16x the resident set so that the hardware dispatcher still balances
     // (measured on TM2048: 21.7 / 25.0 / 27.2 / 27.7 M codewords/s at 1x / 2x / 8x / 64x).
-    const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF>();
+    const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN>();
     size_t grid = resident <= 256 ? resident : resident * 16;
     if (grid > groups) grid = groups;
-    hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
+    hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
                        llrs, output, iters, success, (uint32_t)batch, maxiters);
     return hipGetLastError();
 }

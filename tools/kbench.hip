@@ -20,6 +20,9 @@
 #ifndef KT
 #define KT float
 #endif
+#ifndef KLEAN
+#define KLEAN false
+#endif
 #ifndef KPF
 #define KPF false
 #endif
@@ -50,7 +53,7 @@ int main()
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
+        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep > 0 && ms < best) best = ms;
