@@ -7,8 +7,12 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 
 #include "../../include/labrador_ldpc_hip.h"
@@ -108,12 +112,178 @@ struct StagingPool {
 };
 thread_local StagingPool g_pool;
 
-struct DeviceBuffer {                                 // a view into the calling thread's staging pool
-    void *p = nullptr;
-    int idx;
-    explicit DeviceBuffer(int slot) : idx(slot) {}
-    hipError_t alloc(size_t bytes) { return g_pool.get(idx, bytes, &p); }
+// ---- host-pointer pipeline -----------------------------------------------------------------------
+// The entry points that take HOST buffers stage them through the GPU in chunks.  With more than
+// one chunk the three legs run on three streams -- host->device copy of chunk c+1, kernel of chunk
+// c, device->host copy of chunk c's results (issued from a collector thread: pageable copies block
+// their caller) -- with two sets of staging buffers, so the call runs at max(copy, kernel) per
+// chunk instead of their sum (TM8192 f32 is copy-bound: 32 KB of LLRs in,
+// 1.3 KB out per frame).  One chunk (the reference-shaped single-frame calls) takes the plain
+// copy / launch / copy sequence on the caller's stream.
+struct PipeStreams {                                  // per calling thread, per device
+    int dev = -1;
+    hipStream_t in = nullptr, run = nullptr, out = nullptr;
+    hipEvent_t ev_in[2] = {}, ev_run[2] = {};
+    void drop()
+    {
+        if (dev < 0) return;
+        (void)hipStreamDestroy(in); (void)hipStreamDestroy(run); (void)hipStreamDestroy(out);
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(ev_in[i]); (void)hipEventDestroy(ev_run[i]); }
+        dev = -1;
+    }
+    hipError_t ensure()
+    {
+        int cur = 0;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return e;
+        if (dev == cur) return hipSuccess;
+        drop();
+        hipStream_t *st[3] = {&in, &run, &out};
+        for (auto *sp : st)
+            if ((e = hipStreamCreateWithFlags(sp, hipStreamNonBlocking)) != hipSuccess) return e;
+        for (int i = 0; i < 2; ++i) {
+            if ((e = hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_run[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        dev = cur;
+        return hipSuccess;
+    }
+    ~PipeStreams() { drop(); }
 };
+thread_local PipeStreams g_pipe;
+
+struct HostOut { void *host; size_t bytes_per_item; };
+
+// frames per chunk: about 128 MB of input, at least 8192 frames (the persistent kernels want
+// tens of codewords per workgroup), at most 262144
+// (LABRADOR_LDPC_HIP_CHUNK=<frames> overrides, for tests and tuning).
+size_t chunk_items(size_t in_bytes_per_item)
+{
+    if (const char *env = std::getenv("LABRADOR_LDPC_HIP_CHUNK")) {
+        const long v = std::atol(env);
+        if (v > 0) return (size_t)v;
+    }
+    size_t c = ((size_t)128 << 20) / (in_bytes_per_item ? in_bytes_per_item : 1);
+    if (c < 8192) c = 8192;
+    if (c > 262144) c = 262144;
+    return c;
+}
+
+// launch(d_in, d_out[NOUT], first_item, n_items, stream) -> status code (0 = ok, error text set by the callee)
+template <int NOUT, class Launch>
+int host_pipeline(const void *in, size_t in_bytes_per_item, const HostOut (&outs)[NOUT], size_t items,
+                  hipStream_t user_stream, Launch launch)
+{
+    static_assert(NOUT >= 1 && NOUT <= 3, "two staging sets of 1 + NOUT buffers share the 8 pool slots");
+    const size_t chunk_max = chunk_items(in_bytes_per_item);
+    const size_t chunk = items < chunk_max ? items : chunk_max;
+    const size_t nchunks = (items + chunk - 1) / chunk;
+    const int nsets = nchunks > 1 ? 2 : 1;
+    void *d_in[2] = {}, *d_out[2][NOUT] = {};
+    for (int s = 0; s < nsets; ++s) {
+        HIP_TRY(g_pool.get(4 * s, chunk * in_bytes_per_item, &d_in[s]));
+        for (int o = 0; o < NOUT; ++o) HIP_TRY(g_pool.get(4 * s + 1 + o, chunk * outs[o].bytes_per_item, &d_out[s][o]));
+    }
+    const char *src = static_cast<const char *>(in);
+
+    if (nchunks == 1) {
+        HIP_TRY(hipMemcpyAsync(d_in[0], src, items * in_bytes_per_item, hipMemcpyHostToDevice, user_stream));
+        if (int st = launch(d_in[0], d_out[0], (size_t)0, items, user_stream)) return st;
+        for (int o = 0; o < NOUT; ++o)
+            HIP_TRY(hipMemcpyAsync(outs[o].host, d_out[0][o], items * outs[o].bytes_per_item, hipMemcpyDeviceToHost, user_stream));
+        HIP_TRY(hipStreamSynchronize(user_stream));
+        return LABRADOR_LDPC_HIP_OK;
+    }
+
+    HIP_TRY(g_pipe.ensure());
+    PipeStreams &ps = g_pipe;
+    hipStream_t s_run = user_stream ? user_stream : ps.run;      // the legacy null stream would serialise the three legs
+    struct Quiesce {                                             // nothing of ours may still touch the caller's memory on return
+        hipStream_t a, b, c;
+        ~Quiesce() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); }
+    } quiesce{ps.in, s_run, ps.out};
+
+    // The copies to and from ordinary (pageable) host memory block the calling thread, so the
+    // copy-out leg gets a thread of its own: this thread keeps the host->device copies back to
+    // back (the leg that bounds the call), the collector drains results behind the kernels.
+    struct Shared {
+        std::mutex m;
+        std::condition_variable cv;
+        size_t issued = 0, collected = 0;          // chunks whose kernel is enqueued / whose results are out
+        bool abort = false;
+        int status = LABRADOR_LDPC_HIP_OK;
+        std::string err;
+    } sh;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+
+    std::thread collector([&] {
+        int st = LABRADOR_LDPC_HIP_OK;
+        auto body = [&]() -> int {
+            HIP_TRY(hipSetDevice(dev));
+            for (size_t c = 0; c < nchunks; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(sh.m);
+                    sh.cv.wait(lk, [&] { return sh.issued > c || sh.abort; });
+                    if (sh.issued <= c) return LABRADOR_LDPC_HIP_OK;           // the issuing side failed
+                }
+                const int s = (int)(c & 1);
+                const size_t f0 = c * chunk, nb = items - f0 < chunk ? items - f0 : chunk;
+                HIP_TRY(hipStreamWaitEvent(ps.out, ps.ev_run[s], 0));
+                for (int o = 0; o < NOUT; ++o)
+                    HIP_TRY(hipMemcpyAsync(static_cast<char *>(outs[o].host) + f0 * outs[o].bytes_per_item, d_out[s][o],
+                                           nb * outs[o].bytes_per_item, hipMemcpyDeviceToHost, ps.out));
+                HIP_TRY(hipStreamSynchronize(ps.out));
+                {
+                    std::lock_guard<std::mutex> lk(sh.m);
+                    sh.collected = c + 1;
+                }
+                sh.cv.notify_all();
+            }
+            return LABRADOR_LDPC_HIP_OK;
+        };
+        st = body();
+        if (st != LABRADOR_LDPC_HIP_OK) {
+            std::lock_guard<std::mutex> lk(sh.m);
+            sh.abort = true; sh.status = st; sh.err = g_err;                   // g_err is this thread's own copy
+        }
+        sh.cv.notify_all();
+    });
+
+    auto issue_all = [&]() -> int {
+        for (size_t c = 0; c < nchunks; ++c) {
+            const int s = (int)(c & 1);
+            const size_t f0 = c * chunk, nb = items - f0 < chunk ? items - f0 : chunk;
+            if (c >= 2) {                                                      // staging set s is free once chunk c-2 is out
+                std::unique_lock<std::mutex> lk(sh.m);
+                sh.cv.wait(lk, [&] { return sh.collected + 2 > c || sh.abort; });
+                if (sh.abort) return LABRADOR_LDPC_HIP_OK;                     // the collector's status is reported below
+            }
+            HIP_TRY(hipMemcpyAsync(d_in[s], src + f0 * in_bytes_per_item, nb * in_bytes_per_item, hipMemcpyHostToDevice, ps.in));
+            HIP_TRY(hipEventRecord(ps.ev_in[s], ps.in));
+            HIP_TRY(hipStreamWaitEvent(s_run, ps.ev_in[s], 0));
+            if (int st = launch(d_in[s], d_out[s], f0, nb, s_run)) return st;
+            HIP_TRY(hipEventRecord(ps.ev_run[s], s_run));
+            {
+                std::lock_guard<std::mutex> lk(sh.m);
+                sh.issued = c + 1;
+            }
+            sh.cv.notify_all();
+        }
+        return LABRADOR_LDPC_HIP_OK;
+    };
+    const int st_issue = issue_all();
+    if (st_issue != LABRADOR_LDPC_HIP_OK) {
+        std::lock_guard<std::mutex> lk(sh.m);
+        sh.abort = true;
+    }
+    sh.cv.notify_all();
+    collector.join();
+    if (st_issue != LABRADOR_LDPC_HIP_OK) return st_issue;
+    if (sh.status != LABRADOR_LDPC_HIP_OK) { g_err = sh.err; return sh.status; }
+    HIP_TRY(hipStreamSynchronize(s_run));
+    return LABRADOR_LDPC_HIP_OK;
+}
 
 template <class T>
 int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
@@ -142,28 +312,17 @@ int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint
     }
     if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
 
-    // host buffers: stage in chunks so that arbitrarily large batches fit
-    const size_t chunk_max = (size_t)1 << 16;
-    const size_t chunk = batch < chunk_max ? batch : chunk_max;
-    DeviceBuffer d_llr(0), d_out(1), d_it(2), d_ok(3);
-    HIP_TRY(d_llr.alloc(chunk * n * sizeof(T)));
-    HIP_TRY(d_out.alloc(chunk * out_len));
-    HIP_TRY(d_it.alloc(chunk * sizeof(uint32_t)));
-    HIP_TRY(d_ok.alloc(chunk));
-    for (size_t f0 = 0; f0 < batch; f0 += chunk) {
-        const size_t nb = batch - f0 < chunk ? batch - f0 : chunk;
-        HIP_TRY(hipMemcpyAsync(d_llr.p, llrs + f0 * n, nb * n * sizeof(T), hipMemcpyHostToDevice, stream));
-        hipError_t e = ldpc::launch_decode_ms<T>(code, variant, (const T *)d_llr.p, (uint8_t *)d_out.p,
-                                                 (uint32_t *)d_it.p, (uint8_t *)d_ok.p, nb, maxit, stream);
+    // host buffers: staged in chunks (arbitrarily large batches fit), copies overlapped with the kernel
+    const HostOut outs[3] = {{output, out_len}, {iters, sizeof(uint32_t)}, {success, 1}};
+    return host_pipeline<3>(llrs, n * sizeof(T), outs, batch, stream,
+                            [&](void *d_in, void *const *d_out, size_t, size_t nb, hipStream_t st) -> int {
+        hipError_t e = ldpc::launch_decode_ms<T>(code, variant, (const T *)d_in, (uint8_t *)d_out[0], (uint32_t *)d_out[1],
+                                                 (uint8_t *)d_out[2], nb, maxit, st);
         if (e == hipErrorInvalidConfiguration)
             return fail(LABRADOR_LDPC_HIP_EUNSUPPORTED, "kernel variant %d not built for code %d", variant, code);
         if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "kernel launch: %s", hipGetErrorString(e));
-        HIP_TRY(hipMemcpyAsync(output + f0 * out_len, d_out.p, nb * out_len, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(iters + f0, d_it.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(success + f0, d_ok.p, nb, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
-    return LABRADOR_LDPC_HIP_OK;
+        return LABRADOR_LDPC_HIP_OK;
+    });
 }
 
 // capi/src/lib.rs:83-95: one frame, host pointers, optional iteration count
@@ -265,20 +424,14 @@ int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code c, const uint8_t *inpu
         return LABRADOR_LDPC_HIP_OK;
     }
     if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
-    DeviceBuffer d_in(0), d_out(1), d_it(2), d_ok(3);
-    HIP_TRY(d_in.alloc(batch * in_len));
-    HIP_TRY(d_out.alloc(batch * out_len));
-    HIP_TRY(d_it.alloc(batch * sizeof(uint32_t)));
-    HIP_TRY(d_ok.alloc(batch));
-    HIP_TRY(hipMemcpyAsync(d_in.p, input, batch * in_len, hipMemcpyHostToDevice, stream));
-    hipError_t e = ldpc::launch_decode_bf(c, (const uint8_t *)d_in.p, (uint8_t *)d_out.p, (uint32_t *)d_it.p,
-                                          (uint8_t *)d_ok.p, batch, maxit, stream);
-    if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "decode_bf launch: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(output, d_out.p, batch * out_len, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(iters, d_it.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(success, d_ok.p, batch, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return LABRADOR_LDPC_HIP_OK;
+    const HostOut outs[3] = {{output, out_len}, {iters, sizeof(uint32_t)}, {success, 1}};
+    return host_pipeline<3>(input, in_len, outs, batch, stream,
+                            [&](void *d_in, void *const *d_out, size_t, size_t nb, hipStream_t st) -> int {
+        hipError_t e = ldpc::launch_decode_bf(c, (const uint8_t *)d_in, (uint8_t *)d_out[0], (uint32_t *)d_out[1],
+                                              (uint8_t *)d_out[2], nb, maxit, st);
+        if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "decode_bf launch: %s", hipGetErrorString(e));
+        return LABRADOR_LDPC_HIP_OK;
+    });
 }
 
 bool labrador_ldpc_decode_bf(enum labrador_ldpc_code c, const uint8_t *input, uint8_t *output, uint8_t *,
@@ -367,15 +520,13 @@ int labrador_ldpc_encode_batch(enum labrador_ldpc_code c, const uint8_t *data, u
         return LABRADOR_LDPC_HIP_OK;
     }
     if (opts && opts->memory != LABRADOR_LDPC_HIP_MEM_HOST) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
-    DeviceBuffer d_in(0), d_out(1);
-    HIP_TRY(d_in.alloc(batch * kb));
-    HIP_TRY(d_out.alloc(batch * nb));
-    HIP_TRY(hipMemcpyAsync(d_in.p, data, batch * kb, hipMemcpyHostToDevice, stream));
-    hipError_t e = ldpc::launch_encode(c, (const uint8_t *)d_in.p, (uint8_t *)d_out.p, batch, stream);
-    if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "encode launch: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(codewords, d_out.p, batch * nb, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return LABRADOR_LDPC_HIP_OK;
+    const HostOut outs[1] = {{codewords, nb}};
+    return host_pipeline<1>(data, kb, outs, batch, stream,
+                            [&](void *d_in, void *const *d_out, size_t, size_t items, hipStream_t st) -> int {
+        hipError_t e = ldpc::launch_encode(c, (const uint8_t *)d_in, (uint8_t *)d_out[0], items, st);
+        if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "encode launch: %s", hipGetErrorString(e));
+        return LABRADOR_LDPC_HIP_OK;
+    });
 }
 
 int labrador_ldpc_decode_ms_batch_f64(enum labrador_ldpc_code c, const double *llrs, uint8_t *output, uint32_t *iters,

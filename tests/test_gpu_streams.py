@@ -34,15 +34,73 @@ def test_non_default_stream_is_honoured():
 
 
 def test_host_batch_larger_than_one_staging_chunk():
-    """MEM_HOST calls stage 65 536 frames at a time (csrc/capi.hip)."""
+    """MEM_HOST calls stage at most 262 144 frames at a time (csrc/capi.hip chunk_items)."""
     code = LDPCCode.TC128
     rng = np.random.default_rng(2)
     base, _ = oracle.awgn_llrs(code, rng, 1024, 3.0, np.float32)
-    llrs = np.tile(base, (70, 1))[: 65536 + 4097]
+    llrs = np.tile(base, (261, 1))[: 262144 + 4097]
     out, it, ok = code.decode_ms_batch(llrs, 25)
     ref_out, ref_it, ref_ok, _ = oracle.decode_ms_batch(code, base, 25)
     idx = np.arange(len(llrs)) % 1024
     assert (out == ref_out[idx]).all() and (it == ref_it[idx]).all() and (ok == ref_ok[idx]).all()
+
+
+@pytest.fixture
+def small_chunks(monkeypatch):
+    monkeypatch.setenv("LABRADOR_LDPC_HIP_CHUNK", "300")      # read by the library on every host-pointer call
+    yield 300
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16, np.float64])
+@pytest.mark.parametrize("frames", [300, 301, 599, 600, 1501])
+def test_host_pipeline_decode_ms_matches_oracle(small_chunks, dtype, frames):
+    """1, 2 (one ragged), 2, and 6 chunks through the three-stream host pipeline; every frame distinct."""
+    code = LDPCCode.TM1280
+    rng = np.random.default_rng(frames)
+    llrs, _ = oracle.awgn_llrs(code, rng, frames, 3.5, dtype)
+    out, it, ok = code.decode_ms_batch(llrs, 20)
+    ref_out, ref_it, ref_ok, _ = oracle.decode_ms_batch(code, llrs, 20)
+    assert (out == ref_out).all() and (it == ref_it).all() and (ok == ref_ok).all()
+
+
+def test_host_pipeline_on_a_caller_stream_and_from_two_threads(small_chunks):
+    import threading
+    code = LDPCCode.TM1536
+    rng = np.random.default_rng(77)
+    llrs, _ = oracle.awgn_llrs(code, rng, 1000, 3.0, np.float32)
+    ref = oracle.decode_ms_batch(code, llrs, 20)
+    s = torch.cuda.Stream(device=torch.device("cuda", 0))
+    out, it, ok = code.decode_ms_batch(llrs, 20, stream=s.cuda_stream)
+    assert (out == ref[0]).all() and (it == ref[1]).all() and (ok == ref[2]).all()
+    results = [None, None]
+
+    def work(k):
+        results[k] = code.decode_ms_batch(llrs[k::2].copy(), 20)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        assert (results[k][0] == ref[0][k::2]).all() and (results[k][1] == ref[1][k::2]).all()
+
+
+def test_host_pipeline_decode_bf_and_encode(small_chunks):
+    code = LDPCCode.TC256
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, size=(1000, code.k() // 8), dtype=np.uint8)
+    cws = code.encode_batch(data)
+    assert cws.shape == (1000, code.n() // 8)
+    for f in (0, 299, 300, 999):
+        assert (cws[f] == oracle.copy_encode(code, data[f])).all()
+    rx = cws.copy()
+    flips = rng.integers(0, code.n(), size=1000)
+    rx[np.arange(1000), flips // 8] ^= (0x80 >> (flips % 8)).astype(np.uint8)
+    out, it, ok = code.decode_bf_batch(rx, 30)
+    for f in (0, 1, 299, 300, 301, 998, 999):
+        r_ok, r_it, r_out = oracle.decode_bf(code, rx[f], 30)
+        assert ok[f] == r_ok and it[f] == r_it and (out[f] == r_out).all()
+    good = ok == 1
+    assert good.mean() > 0.9 and (out[good][:, : code.k() // 8] == data[good]).all()
 
 
 def test_misaligned_device_output_is_rejected():
