@@ -130,3 +130,37 @@ def test_bad_device_and_variant_are_reported():
     st = la.lib.labrador_ldpc_decode_ms_batch_f32(int(code), llrs.ctypes.data, out.ctypes.data, it.ctypes.data,
                                                   ok.ctypes.data, 2, 10, ctypes.byref(opts))
     assert st == -4 and "variant" in la.last_error()
+
+
+def test_device_calls_can_be_captured_in_a_hip_graph():
+    """Device-resident calls only enqueue work on the given stream, so a channel + decode pass can be
+    captured once into a HIP graph and replayed (the launch-bound small-batch case)."""
+    code = LDPCCode.TM1280
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, size=(64, code.k() // 8), dtype=np.uint8)
+    cws = code.encode_batch(torch.from_numpy(data).to(dev))
+    frames = 512
+    llrs = torch.empty((frames, code.n()), dtype=torch.float32, device=dev)
+    out = torch.empty((frames, code.output_len()), dtype=torch.uint8, device=dev)
+    it = torch.empty((frames,), dtype=torch.int32, device=dev)
+    ok = torch.empty((frames,), dtype=torch.uint8, device=dev)
+    sigma = 0.55
+
+    def one_pass():
+        code.awgn_frames(cws, frames, sigma, seed=1234, dtype="f32", out=llrs)
+        code.decode_ms_batch(llrs, 25, output=out, iters=it, success=ok)
+
+    one_pass()                                   # warm-up outside the capture (module load, occupancy query)
+    torch.cuda.synchronize()
+    ref_llrs = llrs.cpu().numpy().copy()
+    ref = oracle.decode_ms_batch(code, ref_llrs, 25)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one_pass()
+    for _ in range(3):
+        llrs.zero_(); out.zero_(); it.zero_(); ok.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (llrs.cpu().numpy() == ref_llrs).all()
+        assert (out.cpu().numpy() == ref[0]).all() and (it.cpu().numpy() == ref[1]).all() and (ok.cpu().numpy() == ref[2]).all()
