@@ -251,6 +251,43 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     }
 };
 
+// f64 LLRs (decoder.rs:78-86): two VGPRs per value, the sign is bit 31 of the HIGH word, so the
+// sign-word machinery (bits / apply_sign) works on that word; no -0.0 either (load adds +0.0).
+// Plain expressions instead of pinned instruction trees: f64 is the least used variant and its
+// VALU ops are quarter rate whatever the tree looks like.
+template <> struct Ops<double> {
+    using R = double;
+    using E = double;
+    LDPC_DEV static R zero() { return 0.0; }
+    LDPC_DEV static R maxval() { return DBL_MAX; }
+    LDPC_DEV static R load(double x) { return x + 0.0; }
+    LDPC_DEV static double store(R x) { return x; }
+    LDPC_DEV static R from_lds(double x) { return x; }
+    LDPC_DEV static int bits(R x) { return __double2hiint(x); }
+    LDPC_DEV static R add(R a, R b) { return a + b; }
+    LDPC_DEV static R sub(R a, R b) { return a - b; }
+    LDPC_DEV static R mag(R x) { return __builtin_fabs(x); }
+    template <bool AX, bool AY>
+    LDPC_DEV static R min2(R x, R y)
+    {
+        const R a = AX ? __builtin_fabs(x) : x, b = AY ? __builtin_fabs(y) : y;
+        return b < a ? b : a;
+    }
+    template <bool AX> LDPC_DEV static R min2_cap(R x) { return min2<AX, false>(x, DBL_MAX); }
+    template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<false, false>(min2<AX, AY>(x, y), DBL_MAX); }
+    template <bool AX, bool AY, bool AZ>
+    LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
+    template <bool FULL_EXEC>
+    LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
+    {
+        return (old != 0.0 && (nv < 0.0) != (old < 0.0)) ? 0.0 : nv;
+    }
+    LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
+    {
+        return __hiloint2double(__double2hiint(m) ^ s_all ^ s_own, __double2loint(m));
+    }
+};
+
 // Integer LLR types run on the float pipeline: i8/i16 values and every intermediate of the
 // algorithm are integers of magnitude <= 2^16, which f32 represents exactly, so saturating
 // add/sub (decoder.rs:47-48, :56-57) are an f32 add/sub followed by a clamp, and all the sign-bit
@@ -860,7 +897,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 // the LLRs are re-read from global memory (L2) every iteration; this brings TM5120 under 128
 // VGPRs so that two workgroups share a CU.
 template <int CODE, class T, int IPT, bool PF, bool LEAN>
-__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (LEAN ? 4 : 1))
+__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (LEAN && sizeof(T) <= 4 ? 4 : 1))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                  uint32_t batch, uint32_t maxiters)

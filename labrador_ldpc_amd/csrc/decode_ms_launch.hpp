@@ -36,8 +36,9 @@ int resident_workgroups()
     return cached[dev];
 }
 
-template <int CODE, class T, int IPT>
-hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+// Launch one instantiation (IPT indices per thread, LEAN = register-lean check phase).
+template <int CODE, class T, int IPT, bool LEAN>
+hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
                       size_t batch, uint32_t maxiters, hipStream_t stream)
 {
     using GEO = Geometry<CODE, T, IPT>;
@@ -45,10 +46,6 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // codeword on TM8192 (4.99 vs 5.29 M codewords/s: the extra live state costs spills at the
     // 128-VGPR budget), so it stays off; see DESIGN.md section 7.
     constexpr bool PF = false;
-    // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
-    // is TM5120 only (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB).  Measured slower
-    // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
-    constexpr bool LEAN = CODE == TM5120 && IPT == 1;
     if (batch == 0) return hipSuccess;
     const size_t groups = (batch + GEO::G - 1) / GEO::G;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
@@ -63,6 +60,17 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
                        llrs, output, iters, success, (uint32_t)batch, maxiters);
     return hipGetLastError();
+}
+
+template <int CODE, class T, int IPT>
+hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                      size_t batch, uint32_t maxiters, hipStream_t stream)
+{
+    // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
+    // is TM5120 only (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB).  Measured slower
+    // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
+    constexpr bool LEAN = CODE == TM5120 && IPT == 1;
+    return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream);
 }
 
 // one `case` of the dispatch switch: default IPT plus optional alternatives

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
+import labrador_ldpc_amd as la
 from labrador_ldpc_amd import LDPCCode
 
 pytestmark = pytest.mark.gpu
@@ -124,3 +125,24 @@ def test_f64_corner_values(code):
     llrs[5, ::7] = np.inf
     llrs[6, ::11] = -np.inf
     _compare(code, llrs, 20)
+
+
+F64_VARIANTS = [(LDPCCode.TC128, 17), (LDPCCode.TC256, 17), (LDPCCode.TC512, 17), (LDPCCode.TM1280, 17), (LDPCCode.TM1536, 17),
+                (LDPCCode.TM2048, 1), (LDPCCode.TM5120, 18), (LDPCCode.TM6144, 18), (LDPCCode.TM6144, 2)]
+
+
+@pytest.mark.parametrize("code,variant", F64_VARIANTS + [(c, 100) for c in ALL], ids=lambda v: getattr(v, "name", str(v)))
+def test_f64_variants(code, variant):
+    """f64: the non-default register-kernel instantiations (IPT = variant & 15, register-lean check phase if
+    variant & 16) and the workspace kernel (variant 100) all agree with the oracle."""
+    rng = np.random.default_rng(41 + int(code))
+    llrs, _ = oracle.awgn_llrs(code, rng, 48, 2.5, np.float64)
+    llrs[0, ::5] = -0.0
+    llrs[1] *= 1e-310
+    _compare(code, llrs, 25, variant=variant)
+
+
+def test_f64_unbuilt_variant_is_reported():
+    code = LDPCCode.TM8192
+    with pytest.raises(la.LdpcHipError, match="variant"):
+        code.decode_ms_batch(np.zeros((2, code.n()), dtype=np.float64), 5, variant=1)   # 176 KB of LDS: not built
