@@ -70,6 +70,26 @@
 #ifndef LDPC_EARLY_FETCH
 #define LDPC_EARLY_FETCH 0
 #endif
+// Progress-based wave priority.  VALU issue is arbitrated by priority, then age, so the oldest wave
+// of a SIMD runs ahead and the youngest arrives last at every barrier, the last stretch of each
+// phase with the SIMD half empty.  Lowering a wave's priority as it advances through a phase
+// (s_setprio 3 -> 0 at about the quarter marks) lets the laggards catch up: TM8192 5.61 -> 6.09,
+// TM6144 9.64 -> 9.94, TM2048 46.9 -> 47.4 M codewords/s.  Only for codewords of 8 or more waves
+// (PRIO_WAVES below): with one or two waves per codeword it costs (TC512 -7 %, TM1280 -1 %).
+// 0 = off, 1 = with a scheduling barrier at each step, 2 = plain.
+#ifndef LDPC_PRIO
+#define LDPC_PRIO 2
+#endif
+#ifndef LDPC_PRIO_VAR
+#define LDPC_PRIO_VAR 2          // priority of the first half of the (short) variable phase
+#endif
+#if LDPC_PRIO == 1
+#define LDPC_SETPRIO(n) do { if constexpr (PRIO_WAVES) { __builtin_amdgcn_s_setprio(n); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#elif LDPC_PRIO == 2
+#define LDPC_SETPRIO(n) do { if constexpr (PRIO_WAVES) __builtin_amdgcn_s_setprio(n); } while (0)
+#else
+#define LDPC_SETPRIO(n) do { } while (0)
+#endif
 #ifdef LDPC_DIAG_FIXED_ITERS
 #define LDPC_DIAG_EARLY_EXIT 0
 #else
@@ -432,6 +452,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr int M = GEO::M, NT = GEO::NT, G = GEO::G, NB = GEO::NB, NROWS = GEO::NROWS,
                   NCOLS = GEO::NCOLS, NTX = GEO::NTX, NX = GEO::NX, NXC = GEO::NXC;
     constexpr int N = CODES[CODE].n;
+    constexpr bool PRIO_WAVES = NT >= 512;       // see LDPC_PRIO
+    (void)PRIO_WAVES;
 
     // LDS, per codeword of the workgroup: [ xu: NX blocks | xva: NXC block columns | 2 flags ]
     //   xu   check -> variable messages of the exchanged blocks, stored at the VARIABLE's index
@@ -619,6 +641,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             constexpr int S = decltype(S_)::value;
             const int i = S * NT + t;
+            if constexpr (S == 0) LDPC_SETPRIO(LDPC_PRIO_VAR);
+            else if constexpr (S == IPT / 2) LDPC_SETPRIO(0);
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
                 constexpr int C = decltype(C_)::value;
                 R acc = O::zero();
@@ -676,6 +700,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         // then stay live across the whole loop (which costs more in spills than it saves).
         int tb = t * SZ;
         asm volatile("" : "+v"(tb));
+        LDPC_SETPRIO(3);
         // Order of work, chosen so that LDS latency is covered by arithmetic: (1) request the
         // marginals of all exchanged edges, (2) update the LOCAL edges (their marginals are in
         // registers), (3) update the exchanged edges as their data arrives, (4) per check:
@@ -699,14 +724,17 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             check_local();                                                             // (2)
             __builtin_amdgcn_sched_barrier(0);
         }
+        LDPC_SETPRIO(2);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], u[S][B]);
             });
         });
+        LDPC_SETPRIO(1);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (4)
             constexpr int S = decltype(S_)::value;
+            if constexpr (S == IPT / 2 && IPT > 1) LDPC_SETPRIO(0);
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
@@ -756,6 +784,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
                 constexpr int CH = 6, NCH = (D + CH - 1) / CH;
+                LDPC_SETPRIO(3 - ((S * NROWS + Rw) * 4) / (IPT * NROWS));
                 int par = 0, sgn = 0;
                 static_for<0, NCH>([&](auto K_) LDPC_INLINE {
                     constexpr int J0 = decltype(K_)::value * CH, J1 = J0 + CH < D ? J0 + CH : D;

@@ -9,7 +9,7 @@ typedef float float2_ __attribute__((ext_vector_type(2)));
 #define REP8(X) X X X X X X X X
 #define BODY(INS) \
     asm volatile(REP8(INS "\n") REP8(INS "\n") REP8(INS "\n") REP8(INS "\n") \
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(p) : "v"(e), "v"(f), "s"(sm), "v"(q) : "vcc");
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(p) : "v"(e), "v"(f), "s"(sm), "v"(q) : "vcc", "s20", "s21", "s22", "s23");
 // operand map: %0-%3 a,b,c,d  %4 p(pair rw)  -> shifted below
 template <int KIND>
 __global__ void __launch_bounds__(1024) spin(float *out, int loops, float seed)
@@ -49,10 +49,40 @@ __global__ void __launch_bounds__(1024) spin(float *out, int loops, float seed)
         if (KIND == 28) { BODY("v_pk_add_i16 %0, %5, %1\n v_pk_add_i16 %1, %6, %2\n v_pk_add_i16 %2, %5, %3\n v_pk_add_i16 %3, %6, %0") }
         if (KIND == 29) { BODY("v_and_b32 %0, %5, %1\n v_and_b32 %1, %6, %2\n v_and_b32 %2, %5, %3\n v_and_b32 %3, %6, %0") }
 
+        // ---- mixes of fast (F: v_xor) and slow (S: v_min_f32) independent ops: what does the order cost? ----
+        if (KIND == 40) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %2, %5, %2\n v_min_f32 %1, %6, %1\n v_min_f32 %3, %6, %3") }                 // FFSS
+        if (KIND == 41) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %2, %5, %2\n v_xor_b32 %0, %6, %0\n v_xor_b32 %2, %6, %2\n"
+                               "v_min_f32 %1, %6, %1\n v_min_f32 %3, %6, %3\n v_min_f32 %1, %5, %1\n v_min_f32 %3, %5, %3") }                // FFFFSSSS
+        if (KIND == 42) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %2, %5, %2\n v_min_f32 %1, %6, %1") }                                          // FFS
+        if (KIND == 43) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %2, %5, %2\n v_xor_b32 %3, %6, %3\n v_min_f32 %1, %6, %1") }                // FFFS
+        if (KIND == 44) { BODY("v_xor_b32 %0, %5, %0\n v_min_f32 %1, %6, %1\n v_min_f32 %3, %6, %3") }                                          // FSS
+        if (KIND == 45) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %0, %6, %0\n v_xor_b32 %0, %5, %0\n v_xor_b32 %0, %6, %0") }                // F dependent chain
+        if (KIND == 46) { BODY("v_min_f32 %1, %6, %1\n v_min_f32 %1, %5, %1\n v_min_f32 %1, %6, %1\n v_min_f32 %1, %5, %1") }                // S dependent chain
+        if (KIND == 47) { BODY("v_cmp_ngt_f32 vcc, 0, %1\n v_xor_b32 %0, %5, %0\n v_cmp_ngt_f32 vcc, 0, %3\n v_xor_b32 %2, %5, %2") }        // cmp F cmp F
+        if (KIND == 48) { BODY("v_cndmask_b32 %1, 0, %0, vcc\n v_xor_b32 %0, %5, %0\n v_cndmask_b32 %3, 0, %2, vcc\n v_xor_b32 %2, %5, %2") }  // cnd F cnd F
+        if (KIND == 49) { BODY("v_cmp_ngt_f32 vcc, 0, %1\n s_nop 1\n v_cndmask_b32 %1, 0, %0, vcc\n v_cmp_ngt_f32 vcc, 0, %3\n s_nop 1\n v_cndmask_b32 %3, 0, %2, vcc") }  // cmp cnd pairs
+        if (KIND == 50) { BODY("v_xor_b32 %0, %5, %0\n v_min3_f32 %1, %6, %1, %5\n v_xor_b32 %2, %5, %2\n v_min3_f32 %3, %6, %3, %5") }      // F min3 alternating
+        if (KIND == 51) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %2, %5, %2\n v_min3_f32 %1, %6, %1, %5\n v_min3_f32 %3, %6, %3, %5") }      // FF min3 min3
+        if (KIND == 52) { BODY("v_sub_f32 %0, %5, %0\n v_min_f32 %1, %6, %1\n v_sub_f32 %2, %5, %2\n v_min_f32 %3, %6, %3") }                // sub/min alternating
+        if (KIND == 53) { BODY("v_bitop3_b32 %0, %5, %0, %6 bitop3:0x96\n v_min_f32 %1, %6, %1\n v_bitop3_b32 %2, %5, %2, %6 bitop3:0x96\n v_min_f32 %3, %6, %3") }  // bitop3/min alternating
+        // ---- the self-correcting edge update of decode_ms (sub, bitop3, cmp, cndmask) on four independent edges ----
+        // 30: as the compiler emits it (one edge after the other through VCC, hazard nops)
+        if (KIND == 30) { BODY("v_sub_f32 %0, %5, %0\n v_bitop3_b32 %1, %1, %0, %7 bitop3:0x78\n v_cmp_ngt_f32 vcc, 0, %1\n s_nop 1\n v_cndmask_b32 %1, 0, %0, vcc\n"
+                               "v_sub_f32 %2, %6, %2\n v_bitop3_b32 %3, %3, %2, %7 bitop3:0x78\n v_cmp_ngt_f32 vcc, 0, %3\n s_nop 1\n v_cndmask_b32 %3, 0, %2, vcc") }
+        // 31: two edges interleaved, compares into separate SGPR pairs (no VCC chain, no nops)
+        if (KIND == 31) { BODY("v_sub_f32 %0, %5, %0\n v_sub_f32 %2, %6, %2\n v_bitop3_b32 %1, %1, %0, %7 bitop3:0x78\n v_bitop3_b32 %3, %3, %2, %7 bitop3:0x78\n"
+                               "v_cmp_ngt_f32_e64 s[20:21], 0, %1\n v_cmp_ngt_f32_e64 s[22:23], 0, %3\n v_cndmask_b32_e64 %1, 0, %0, s[20:21]\n v_cndmask_b32_e64 %3, 0, %2, s[22:23]") }
+        // 32: like 30 without the nops but the second edge's sub/bitop3 between compare and select
+        if (KIND == 32) { BODY("v_sub_f32 %0, %5, %0\n v_bitop3_b32 %1, %1, %0, %7 bitop3:0x78\n v_cmp_ngt_f32 vcc, 0, %1\n v_sub_f32 %2, %6, %2\n v_bitop3_b32 %3, %3, %2, %7 bitop3:0x78\n v_cndmask_b32 %1, 0, %0, vcc\n"
+                               "v_cmp_ngt_f32 vcc, 0, %3\n s_nop 1\n v_cndmask_b32 %3, 0, %2, vcc") }
+        // 33: alternating fast / slow independent ops (does the fast rate survive the mix?)
+        if (KIND == 33) { BODY("v_xor_b32 %0, %5, %0\n v_min_f32 %1, %6, %1\n v_xor_b32 %2, %5, %2\n v_min_f32 %3, %6, %3") }
+        // 34: min3 tree fragment with |abs| modifiers as in exclusive_min
+        if (KIND == 34) { BODY("v_min3_f32 %0, |%5|, |%1|, %6\n v_min3_f32 %1, |%6|, |%2|, %5\n v_min3_f32 %2, |%5|, |%3|, %6\n v_min3_f32 %3, |%6|, |%0|, %5") }
     }
     if (a + b + c + d + p.x == 12345.f) out[0] = a;
 }
-template <int KIND> void run(const char *name)
+template <int KIND> void run(const char *name, int per_group = 4)
 {
     float *d; (void)hipMalloc(&d, 4);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -62,7 +92,7 @@ template <int KIND> void run(const char *name)
     spin<KIND><<<blocks, threads>>>(d, loops, 1.f);
     (void)hipEventRecord(b); (void)hipEventSynchronize(b);
     float ms; (void)hipEventElapsedTime(&ms, a, b);
-    printf("%-26s %.3f ns per wave-instr per SIMD\n", name, ms * 1e6 / ((double)loops * 128 * 4));
+    printf("%-34s %.3f ns per wave-instr per SIMD (%d VALU per group)\n", name, ms * 1e6 / ((double)loops * 32 * per_group * 4), per_group);
 }
 int main()
 {
@@ -97,5 +127,14 @@ int main()
     run<28>("v_pk_add_i16");
     run<29>("v_and_b32");
 
+    run<40>("FFSS", 4); run<41>("FFFFSSSS", 8); run<42>("FFS", 3); run<43>("FFFS", 4); run<44>("FSS", 3);
+    run<45>("F dependent chain", 4); run<46>("S dependent chain", 4); run<47>("cmp F cmp F", 4); run<48>("cnd F cnd F", 4);
+    run<49>("cmp cnd pairs", 4); run<50>("F min3 alternating", 4); run<51>("FF min3 min3", 4); run<52>("sub/min alternating", 4);
+    run<53>("bitop3/min alternating", 4);
+    run<30>("edge update, serial via VCC", 8);
+    run<31>("edge update, 2 interleaved, SGPR", 8);
+    run<32>("edge update, overlapped VCC", 8);
+    run<33>("xor/min alternating", 4);
+    run<34>("v_min3_f32 |abs|", 4);
     return 0;
 }
