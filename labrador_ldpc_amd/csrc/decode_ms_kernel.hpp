@@ -77,6 +77,14 @@
 // TM6144 9.64 -> 9.94, TM2048 46.9 -> 47.4 M codewords/s.  Only for codewords of 8 or more waves
 // (PRIO_WAVES below): with one or two waves per codeword it costs (TC512 -7 %, TM1280 -1 %).
 // 0 = off, 1 = with a scheduling barrier at each step, 2 = plain.
+// Experiment switch: ds_write_addtid_b32 for the stores of the marginals (see lds_store_own): half the
+// LDS cycles of ds_write_b32.  +1 % on TM8192 (6.09 -> 6.15 M codewords/s), but the instruction's base
+// register M0 holds 16 bits, so it is only correct while the workgroup's LDS allocation starts below
+// 64 KB -- true for a lone TM8192 workgroup, false as soon as several workgroups (or another kernel)
+// share the CU (TM2048 decoded wrongly).  Off.
+#ifndef LDPC_ADDTID
+#define LDPC_ADDTID 0
+#endif
 #ifndef LDPC_PRIO
 #define LDPC_PRIO 2
 #endif
@@ -490,6 +498,19 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     auto lds_load = [&](int byte_off) LDPC_INLINE -> E { return lds_at(byte_off); };
     auto lds_store = [&](int byte_off, E val) LDPC_INLINE { lds_at(byte_off) = val; };
 #endif
+    // Store to the thread's OWN position of a block region: ds_write_addtid_b32 takes its address from
+    // M0 + offset + 4 * lane -- no address VGPR to send, 2 LDS cycles per wave instead of 4
+    // (MI355X_MICROARCH.md, LDS).  The compiler does not use M0 in this kernel.
+    constexpr bool ADDTID = LDPC_ADDTID && G == 1 && NT >= 64 && SZ == 4;
+    unsigned wave_lds = 0;                        // LDS byte address of the wave's first lane in block region 0
+    if constexpr (ADDTID)
+        wave_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(__attribute__((address_space(3))) char *)gbase + (unsigned)(t & ~63) * SZ));
+    auto lds_store_own = [&](auto OFF_, E val) LDPC_INLINE {      // OFF_: literal byte offset of index (S * NT + 0)
+        constexpr int off = decltype(OFF_)::value;
+        static_assert(off >= 0 && off < 65536, "ds offset field");
+        const unsigned m0v = wave_lds;            // (named so that the generic lambda captures it)
+        asm volatile("s_mov_b32 m0, %1\n\tds_write_addtid_b32 %0 offset:%2" ::"v"(val), "s"(m0v), "n"(off) : "memory");
+    };
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
@@ -665,7 +686,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int cs = col_slot(P, C);
                 if constexpr (cs >= 0) {
                     constexpr int off = lds_xva_off(P, cs, BLK_BYTES);
-                    lds_store(off + i * SZ, O::store(acc));
+                    if constexpr (ADDTID) lds_store_own(IC<off + S * NT * SZ>{}, O::store(acc));
+                    else lds_store(off + i * SZ, O::store(acc));
                 }
             });
         });

@@ -1,0 +1,172 @@
+"""Generate valu_seq.hip: issue cost of the min-sum check update for one check row of degree 6 under
+different instruction ORDERS (same multiset of instructions, physical registers chosen here).
+    python tools/ubench/gen_seq.py > tools/ubench/valu_seq.hip
+    hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_seq tools/ubench/valu_seq.hip && /tmp/valu_seq [threads]
+
+Per edge k (registers: x_k marginal, u_k message, v_k old value, n_k new value, s_k sign word, e_k min):
+    sub    n = x - u                        F  (f32 add/sub/mul/mov: pairs with anything)
+    t      v = bitop3(v, n, M)              I  (integer / bit ops: pair with F, I, cnd)
+    cmp    vcc = !(0 > v)                   C  (min/max/med3/compares: exclusive, pair only with F)
+    cnd    v = vcc ? n : 0
+    and    s = v & M                        I
+per row: 3 xor3 (I), 9 min3 (C), 6 apply-sign bitop3 (I).
+"""
+D = 6
+ROWS = 3          # rows per asm block (independent register sets; v8..v127)
+
+
+def regs(r):
+    base = 8 + r * 40
+    return dict(x=[base + k for k in range(D)], u=[base + 6 + k for k in range(D)], v=[base + 12 + k for k in range(D)],
+                n=[base + 18 + k for k in range(D)], s=[base + 24 + k for k in range(D)], e=[base + 30 + k for k in range(D)],
+                t=[base + 36 + k for k in range(4)])
+
+
+def ops_row(r):
+    R = regs(r)
+    sub = [f"v_sub_f32 v{R['n'][k]}, v{R['x'][k]}, v{R['u'][k]}" for k in range(D)]
+    tt = [f"v_bitop3_b32 v{R['v'][k]}, v{R['v'][k]}, v{R['n'][k]}, s20 bitop3:0x78" for k in range(D)]
+    cmp_ = [f"v_cmp_ngt_f32 vcc, 0, v{R['v'][k]}" for k in range(D)]
+    cnd = [f"v_cndmask_b32 v{R['v'][k]}, 0, v{R['n'][k]}, vcc" for k in range(D)]
+    and_ = [f"v_and_b32 v{R['s'][k]}, 0x80000000, v{R['v'][k]}" for k in range(D)]
+    xor3 = [f"v_bitop3_b32 v{R['t'][0]}, v{R['s'][0]}, v{R['s'][1]}, v{R['s'][2]} bitop3:0x96",
+            f"v_bitop3_b32 v{R['t'][0]}, v{R['t'][0]}, v{R['s'][3]}, v{R['s'][4]} bitop3:0x96",
+            f"v_xor_b32 v{R['t'][0]}, v{R['t'][0]}, v{R['s'][5]}"]
+    v = R['v']
+    min3 = [f"v_min3_f32 v{R['t'][1]}, |v{v[0]}|, |v{v[1]}|, |v{v[2]}|", f"v_min3_f32 v{R['t'][2]}, |v{v[3]}|, |v{v[4]}|, |v{v[5]}|",
+            f"v_min_f32 v{R['t'][3]}, s21, v{R['t'][2]}"] + \
+           [f"v_min3_f32 v{R['e'][k]}, |v{v[(k + 1) % 3]}|, |v{v[(k + 2) % 3]}|, v{R['t'][3]}" for k in range(3)] + \
+           [f"v_min3_f32 v{R['e'][3 + k]}, |v{v[3 + (k + 1) % 3]}|, |v{v[3 + (k + 2) % 3]}|, v{R['t'][1]}" for k in range(3)]
+    app = [f"v_bitop3_b32 v{R['u'][k]}, v{R['e'][k]}, v{R['t'][0]}, v{R['s'][k]} bitop3:0x96" for k in range(D)]
+    return dict(sub=sub, t=tt, cmp=cmp_, cnd=cnd, and_=and_, xor3=xor3, min3=min3, app=app)
+
+
+def order_compiler(rows):
+    out = []
+    for r in rows:
+        o = ops_row(r)
+        for k in range(D):
+            out += [o['sub'][k], o['t'][k], o['cmp'][k], "s_nop 1", o['cnd'][k], o['and_'][k]]
+        out += o['xor3'] + o['min3'] + o['app']
+    return out
+
+
+def order_runs(rows):
+    """class-homogeneous runs per row"""
+    out = []
+    for r in rows:
+        o = ops_row(r)
+        out += o['sub'] + o['t']
+        for k in range(D):
+            out += [o['cmp'][k], "s_nop 1", o['cnd'][k]]
+        out += o['and_'] + o['xor3'] + o['min3'] + o['app']
+    return out
+
+
+def order_fc(rows):
+    """every C op next to an F op: cmp_k beside sub_{k+1}; the min3 of row r beside the subs of row r+1"""
+    out = []
+    allo = [ops_row(r) for r in rows]
+    n = len(rows)
+    out += allo[0]['sub'][:1]
+    for i, o in enumerate(allo):
+        nxt = allo[i + 1]['sub'] if i + 1 < n else []
+        for k in range(D):
+            out += [o['t'][k], o['cmp'][k]]
+            if k + 1 < D:
+                out += [o['sub'][k + 1]]
+            else:
+                out += ["s_nop 1"]
+            out += [o['cnd'][k], o['and_'][k]]
+        out += o['xor3']
+        m = list(o['min3'])
+        f = list(nxt)
+        while m:
+            out.append(m.pop(0))
+            if f:
+                out.append(f.pop(0))
+        out += f
+        out += o['app']
+        if i + 1 < n:
+            # next row's subs already issued: skip its own
+            allo[i + 1] = dict(allo[i + 1])
+            allo[i + 1]['sub'] = [None] * D
+    return [x for x in out if x]
+
+
+def order_fc2(rows):
+    """like fc, and additionally the I ops of row r (t, and, xor3, apply) kept in runs away from the C ops"""
+    out = []
+    allo = [ops_row(r) for r in rows]
+    n = len(rows)
+    out += allo[0]['sub']
+    for i, o in enumerate(allo):
+        nxt = list(allo[i + 1]['sub']) if i + 1 < n else []
+        out += o['t']
+        for k in range(D):
+            out += [o['cmp'][k]]
+            out += [nxt.pop(0)] if nxt and k % 2 == 0 else ["s_nop 1"]
+            out += [o['cnd'][k]]
+        out += o['and_'] + o['xor3']
+        m = list(o['min3'])
+        while m:
+            out.append(m.pop(0))
+            if nxt:
+                out.append(nxt.pop(0))
+        out += nxt
+        out += o['app']
+    return out
+
+
+ORDERS = [("compiler-like (edge after edge)", order_compiler), ("class runs per row", order_runs),
+          ("C beside F (cmp|sub, min3|next row's sub)", order_fc), ("C beside F, I ops in runs", order_fc2)]
+
+print(r'''// GENERATED by tools/ubench/gen_seq.py -- do not edit.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+template <int KIND>
+__global__ void __launch_bounds__(1024) spin(float *out, int loops)
+{
+    // registers v8..v167 are used by the blocks below; seed them with finite, distinct values
+    asm volatile("v_cvt_f32_u32 v1, v0\n s_mov_b32 s20, 0x80000000\n s_mov_b32 s21, 0x7f7fffff" ::: "v1", "s20", "s21");''')
+for v in range(8, 8 + ROWS * 40):
+    print(f'    asm volatile("v_add_f32 v{v}, {float(v % 7) - 3.0}, v1" ::: "v{v}");')
+print("    for (int l = 0; l < loops; ++l) {")
+clob = ", ".join(f'"v{v}"' for v in range(8, 8 + ROWS * 40))
+nvalu = None
+for kind, (name, fn) in enumerate(ORDERS):
+    seq = fn(list(range(ROWS)))
+    valu = sum(1 for x in seq if x.startswith("v_"))
+    nvalu = valu if nvalu is None else nvalu
+    assert valu == nvalu, (name, valu, nvalu)
+    body = "\\n\"\n            \"".join(seq)
+    print(f'        if (KIND == {kind}) {{ asm volatile("{body}" ::: "vcc", "s20", "s21", {clob}); }}')
+print(r'''    }
+    float r;
+    asm volatile("v_mov_b32 %0, v8" : "=v"(r));
+    if (r == 12345.f) out[0] = r;
+}
+static int g_threads = 1024;
+template <int KIND> void run(const char *name, int valu)
+{
+    static float *d = nullptr;
+    if (!d) (void)hipMalloc(&d, 4);
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    const int loops = 20000, blocks = 256;
+    spin<KIND><<<blocks, g_threads>>>(d, 10);
+    (void)hipEventRecord(a);
+    spin<KIND><<<blocks, g_threads>>>(d, loops);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    const double waves_per_simd = g_threads / 256.0;
+    printf("%-46s %7.1f ns per check row per SIMD, %.3f ns per VALU instruction per SIMD\n", name,
+           ms * 1e6 / ((double)loops * @ROWS@ * waves_per_simd), ms * 1e6 / ((double)loops * valu * waves_per_simd));
+}
+int main(int argc, char **argv)
+{
+    if (argc > 1) g_threads = atoi(argv[1]);
+    printf("%d threads per workgroup, one workgroup per CU; %d VALU instructions per check row of degree 6\n", g_threads, @PERROW@);'''.replace("@ROWS@", str(ROWS)).replace("@PERROW@", str(nvalu // ROWS)))
+for kind, (name, fn) in enumerate(ORDERS):
+    print(f'    run<{kind}>("{name}", {nvalu});')
+print("    return 0;\n}")
