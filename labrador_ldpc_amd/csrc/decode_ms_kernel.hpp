@@ -70,13 +70,6 @@
 #ifndef LDPC_EARLY_FETCH
 #define LDPC_EARLY_FETCH 0
 #endif
-// Progress-based wave priority.  VALU issue is arbitrated by priority, then age, so the oldest wave
-// of a SIMD runs ahead and the youngest arrives last at every barrier, the last stretch of each
-// phase with the SIMD half empty.  Lowering a wave's priority as it advances through a phase
-// (s_setprio 3 -> 0 at about the quarter marks) lets the laggards catch up: TM8192 5.61 -> 6.09,
-// TM6144 9.64 -> 9.94, TM2048 46.9 -> 47.4 M codewords/s.  Only for codewords of 8 or more waves
-// (PRIO_WAVES below): with one or two waves per codeword it costs (TC512 -7 %, TM1280 -1 %).
-// 0 = off, 1 = with a scheduling barrier at each step, 2 = plain.
 // Experiment switch: ds_write_addtid_b32 for the stores of the marginals (see lds_store_own): half the
 // LDS cycles of ds_write_b32.  +1 % on TM8192 (6.09 -> 6.15 M codewords/s), but the instruction's base
 // register M0 holds 16 bits, so it is only correct while the workgroup's LDS allocation starts below
@@ -85,8 +78,23 @@
 #ifndef LDPC_ADDTID
 #define LDPC_ADDTID 0
 #endif
+// Progress-based wave priority.  VALU issue is arbitrated by priority, then age, so the oldest wave
+// of a SIMD runs ahead and the youngest arrives last at every barrier, the last stretch of each
+// phase with the SIMD half empty.  Lowering a wave's priority as it advances through a phase
+// lets the laggards catch up.  The schedule that measured best keeps priority 3 through the edge
+// updates and steps down over the last check rows (LDPC_PRIO_ROWS; a sweep of a dozen schedules spans
+// 6.06-6.40 M codewords/s on TM8192, the inverted one 5.54): TM8192 5.61 -> 6.40, TM6144 9.64 ->
+// 10.83, TM2048 46.9 -> 48.1, TM5120 13.76 -> 14.02 M codewords/s.  Only for codewords of 8 or more waves
+// (PRIO_WAVES below): with one or two waves per codeword it costs (TC512 -7 %, TM1280 -1 %).
+// 0 = off, 1 = with a scheduling barrier at each step, 2 = plain.
 #ifndef LDPC_PRIO
 #define LDPC_PRIO 2
+#endif
+#ifndef LDPC_PRIO_ROWS
+#define LDPC_PRIO_ROWS {2, 2, 1, 1, 1, 0}   // priority during the last six (index, check row) steps of the check phase
+#endif
+#ifndef LDPC_PRIO_ROWS_LEAN
+#define LDPC_PRIO_ROWS_LEAN {3, 3, 3, 2, 1, 0}   // the same for the register-lean check phase
 #endif
 #ifndef LDPC_PRIO_VAR
 #define LDPC_PRIO_VAR 2          // priority of the first half of the (short) variable phase
@@ -746,20 +754,24 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             check_local();                                                             // (2)
             __builtin_amdgcn_sched_barrier(0);
         }
-        LDPC_SETPRIO(2);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], u[S][B]);
             });
         });
-        LDPC_SETPRIO(1);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (4)
             constexpr int S = decltype(S_)::value;
-            if constexpr (S == IPT / 2 && IPT > 1) LDPC_SETPRIO(0);
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
+                {   // priority of this (index, row) step: LDPC_PRIO_ROWS lists it for the LAST 6 steps of the phase
+                    constexpr int prio_rows[6] = LDPC_PRIO_ROWS;
+                    constexpr int step = S * NROWS + Rw, nsteps = IPT * NROWS;
+                    constexpr int k = step - (nsteps - 6);
+                    constexpr int now = k >= 0 ? prio_rows[k] : 3, before = (step > 0 && k >= 1) ? prio_rows[k - 1] : 3;
+                    if constexpr (now != before) LDPC_SETPRIO(now);
+                }
                 R a[D], e[D];
                 int sr[D], xw[D];
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
@@ -806,7 +818,13 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
                 constexpr int CH = 6, NCH = (D + CH - 1) / CH;
-                LDPC_SETPRIO(3 - ((S * NROWS + Rw) * 4) / (IPT * NROWS));
+                {
+                    constexpr int prio_rows[6] = LDPC_PRIO_ROWS_LEAN;
+                    constexpr int step = S * NROWS + Rw, nsteps = IPT * NROWS;
+                    constexpr int k = step - (nsteps - 6);
+                    constexpr int now = k >= 0 ? prio_rows[k] : 3, before = (step > 0 && k >= 1) ? prio_rows[k - 1] : -1;
+                    if constexpr (now != before) LDPC_SETPRIO(now);
+                }
                 int par = 0, sgn = 0;
                 static_for<0, NCH>([&](auto K_) LDPC_INLINE {
                     constexpr int J0 = decltype(K_)::value * CH, J1 = J0 + CH < D ? J0 + CH : D;
