@@ -132,6 +132,7 @@ def main():
         bytes_per_launch = F * algorithmic_bytes_per_codeword(code, itemsize)
         achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -140,6 +141,15 @@ def main():
                 key = f"{args.code}_{args.dtype}"
                 if key in t and t[key].get("frames"):
                     traffic = t[key]["hbm_bytes_per_launch"] * (F / t[key]["frames"])
+                    if t[key].get("valu_insts_per_launch"):
+                        # The limiter this kernel actually runs into: wave-level VALU instructions
+                        # (PMC SQ_INSTS_VALU of the profiled launch, scaled to this one) against the issue peak of
+                        # 256 CUs x 4 SIMDs x 2 wave-instructions per 4 cycles at 2.4 GHz.
+                        insts = t[key]["valu_insts_per_launch"] * (F / t[key]["frames"])
+                        peak = 256 * 4 * 2 / 4 * 2.4                                  # G wave-instructions/s
+                        ach = insts / (kernel_ms_max * 1e-3) / 1e9
+                        valu = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                                "source": "SQ_INSTS_VALU per frame from profiles/ (same code, Eb/N0 and iteration cap)"}
             except Exception:
                 traffic = None
         result = {
@@ -160,6 +170,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "decode_ms_kernel", "kernel_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
+            "valu_issue": valu,
             "diag": {"mean_iters_returned": mean_iters, "frame_failure_rate": frame_fail,
                      "edge_visits_per_s": world * F * args.steps / elapsed * 2 * code.paritycheck_sum() * (mean_iters + 1)},
         }

@@ -118,8 +118,100 @@ def order_fc2(rows):
     return out
 
 
+def order_fc_intra(rows):
+    """cmp_k beside sub_{k+1} inside a row only (what one inline-asm block per row can do)"""
+    out = []
+    for r in rows:
+        o = ops_row(r)
+        out += [o['sub'][0]]
+        for k in range(D):
+            out += [o['t'][k], o['cmp'][k]]
+            out += [o['sub'][k + 1]] if k + 1 < D else ["s_nop 1"]
+            out += [o['cnd'][k], o['and_'][k]]
+        out += o['xor3'] + o['min3'] + o['app']
+    return out
+
+
+def order_fc_intra2(rows):
+    """as fc_intra, and the apply-sign bit ops of the row moved between the min3 (I next to C: expected worse)"""
+    out = []
+    for r in rows:
+        o = ops_row(r)
+        out += [o['sub'][0]]
+        for k in range(D):
+            out += [o['t'][k], o['cmp'][k]]
+            out += [o['sub'][k + 1]] if k + 1 < D else ["s_nop 1"]
+            out += [o['cnd'][k], o['and_'][k]]
+        out += o['xor3'] + o['min3'][:3]
+        for k in range(D):
+            out += [o['min3'][3 + k], o['app'][k]]
+    return out
+
+
+def _pipelined(rows, first):
+    """two independent instructions between every v_cmp and its v_cndmask (the VCC hazard needs 2 wait
+    states), taken from the next edges' sub / bit-op; `first` = which of them follows the compare"""
+    out = []
+    for r in rows:
+        o = ops_row(r)
+        pend = []                                   # instructions not yet issued, in dependency order per edge
+        for k in range(D):
+            pend += [("sub", k), ("t", k)]
+        issued = set()
+
+        def take(kind_pref, need_before):
+            for pref in kind_pref:
+                for it in pend:
+                    kind, k = it
+                    if kind != pref:
+                        continue
+                    if kind == "t" and ("sub", k) not in issued:
+                        continue
+                    pend.remove(it)
+                    issued.add(it)
+                    return o[kind][k]
+            return None
+        # prologue: edge 0 ready for its compare
+        out += [take(["sub"], 0), take(["t"], 0)]
+        ands = []
+        for k in range(D):
+            if ("t", k) not in issued:
+                x = take(["sub"], 0) if ("sub", k) not in issued else None
+                if x:
+                    out.append(x)
+                out.append(take(["t"], 0))
+            out.append(o['cmp'][k])
+            fill = []
+            for pref in (first, ["sub", "t"]):
+                x = take(pref, 0)
+                if x:
+                    fill.append(x)
+                if len(fill) == 2:
+                    break
+            while len(fill) < 2 and ands:
+                fill.append(ands.pop(0))
+            out += fill
+            if len(fill) < 2:
+                out.append("s_nop %d" % (1 - len(fill)))
+            out.append(o['cnd'][k])
+            ands.append(o['and_'][k])
+        out += ands
+        out += o['xor3'] + o['min3'] + o['app']
+    return out
+
+
+def order_pipe_f(rows):
+    return _pipelined(rows, ["sub"])
+
+
+def order_pipe_i(rows):
+    return _pipelined(rows, ["t"])
+
+
 ORDERS = [("compiler-like (edge after edge)", order_compiler), ("class runs per row", order_runs),
-          ("C beside F (cmp|sub, min3|next row's sub)", order_fc), ("C beside F, I ops in runs", order_fc2)]
+          ("C beside F (cmp|sub, min3|next row's sub)", order_fc), ("C beside F, I ops in runs", order_fc2),
+          ("cmp|sub inside the row only", order_fc_intra), ("same, apply-sign between the min3", order_fc_intra2),
+          ("2 fillers after each cmp, sub first", order_pipe_f), ("2 fillers after each cmp, bit-op first", order_pipe_i)]
 
 print(r'''// GENERATED by tools/ubench/gen_seq.py -- do not edit.
 #include <hip/hip_runtime.h>
