@@ -1,10 +1,12 @@
 // decode_ms_f64.hip -- f64 min-sum decoder (decode_ms::<f64>, /root/reference/src/decoder.rs:78-86,
 // :347-475; C entry capi/src/lib.rs:121-127).
 //
-// Every code but TM8192 runs the register-resident kernel of decode_ms_kernel.hpp with 64-bit
-// registers and LDS elements (decode_ms_f64_reg.hip; 7-40x faster than the kernel below).  TM8192's
-// f64 exchange arrays (176 KB) exceed the 160 KB of LDS, and f64 LLRs are the least used variant of
-// the reference's API, so for that code (and as `variant` 100 for all) this kernel trades
+// By default every code runs the register-resident kernel of decode_ms_kernel.hpp with 64-bit
+// registers and LDS elements (decode_ms_f64_reg.hip): plain for the small codes, register-lean for
+// TM2048 / TM5120, "in place" (no array of marginals, v kept as sign/zero bit masks) for TM6144 and
+// TM8192, whose f64 exchange arrays would not fit the LDS otherwise.  f64 LLRs are the least used
+// variant of the reference's API; the kernel below is the general fallback (`variant` 100, 10-100x
+// slower) that trades
 // speed for generality: one workgroup per codeword, marginals in LDS, the per-edge messages u and v
 // in a global-memory workspace (edge e = block * M + check index: coalesced), per-check minima in
 // registers of the thread that owns the check.  Same block lists, same arithmetic order:
@@ -169,11 +171,11 @@ hipError_t launch_f64(const double *llrs, uint8_t *output, uint32_t *iters, uint
 
 }  // namespace
 
-hipError_t launch_decode_ms_f64_reg(int code, int ipt, bool lean, const double *llrs, uint8_t *output, uint32_t *iters,
+hipError_t launch_decode_ms_f64_reg(int code, int ipt, int lean, const double *llrs, uint8_t *output, uint32_t *iters,
                                     uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
 
 // variant: 0 = tuned default; 100 = the workspace kernel above; otherwise the register kernel with
-// IPT = variant & 15 and the register-lean check phase if variant & 16.
+// IPT = variant & 15, the register-lean check phase if variant & 16, in-place messages if variant & 32.
 template <>
 hipError_t launch_decode_ms<double>(int code, int variant, const double *llrs, uint8_t *output, uint32_t *iters,
                                     uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
@@ -181,11 +183,11 @@ hipError_t launch_decode_ms<double>(int code, int variant, const double *llrs, u
     if (batch == 0) return hipSuccess;
     if (!valid_code(code)) return hipErrorInvalidValue;
     if (variant == 0) {
-        static constexpr int tuned[NUM_CODES] = {1, 1, 1, 1, 1, 17, 17, 17, 100};
+        static constexpr int tuned[NUM_CODES] = {1, 1, 1, 1, 1, 17, 17, 33, 34};
         variant = tuned[code];
     }
     if (variant != 100)
-        return launch_decode_ms_f64_reg(code, variant & 15, (variant & 16) != 0, llrs, output, iters, success, batch,
+        return launch_decode_ms_f64_reg(code, variant & 15, (variant & 32) ? 2 : ((variant & 16) ? 1 : 0), llrs, output, iters, success, batch,
                                         maxiters, stream);
     switch (code) {
         case TC128:  return launch_f64<TC128>(llrs, output, iters, success, batch, maxiters, stream);

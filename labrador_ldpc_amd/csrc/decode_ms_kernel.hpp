@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
+#include <type_traits>
 
 #include "codes.hpp"
 
@@ -456,7 +457,7 @@ LDPC_DEV int pi_dev(int i, int j)
 // JW >= 0: the body is specialised for waves whose indices start in quarter JW (the kernel
 // branches once, wave-uniformly, into the matching copy) so that every rotation constant of the
 // pi_k blocks is a literal; JW < 0: generic body, constants in SGPRs.
-template <int CODE, class T, int IPT, bool PF, bool LEAN, int JW>
+template <int CODE, class T, int IPT, bool PF, int LEAN, int JW>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                              uint32_t batch, uint32_t maxiters, char *lds, char *stage)
@@ -481,8 +482,14 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // slot and its xva column are less than 64 KB apart: one address register (biased by the
     // lower of the two region offsets, lds_bias()) then serves both accesses through the 16-bit
     // instruction offset.
-    constexpr int FLAG_OFF = (NX + NXC) * M * SZ;
+    // In-place mode (LEAN == 2): [ xu: NX blocks | hi: NXC block columns of 4-byte sign words | flags ].
+    // The variable thread overwrites each exchanged u with nv = va - u in the slot it read it from,
+    // and publishes the high word (sign) of each exchanged marginal; no array of marginals.
+    constexpr bool INPLACE = LEAN == 2;
     constexpr int BLK_BYTES = M * SZ;
+    constexpr int FLAG_OFF = INPLACE ? NX * BLK_BYTES + NXC * M * 4 : (NX + NXC) * M * SZ;
+    auto hi_off = [](int cs) constexpr { return NX * BLK_BYTES + cs * M * 4; };
+    (void)hi_off;
     constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16;
     static_assert(!PF || (G == 1 && NT >= 64), "LLR staging needs whole waves per codeword");
     constexpr int TSZ = sizeof(T);
@@ -563,7 +570,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     const int j = S * (NT / Q) + jw;
                     const int phi = j == 0 ? phi_of(K, 0, M) : (j == 1 ? phi_of(K, 1, M) : (j == 2 ? phi_of(K, 2, M) : phi_of(K, 3, M)));
                     rot_s[S][B] = (phi + S * NT) * SZ;
-                    constexpr int bias = lds_bias(P, B, BLK_BYTES);
+                    constexpr int bias = INPLACE ? exch_slot(P, B) * BLK_BYTES : lds_bias(P, B, BLK_BYTES);
                     base_s[S][B] = (((theta_of(K) + j) & 3) << LQ) * SZ + bias;
                 }
             });
@@ -572,7 +579,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     auto wire = [&](auto B_, auto S_, int tb) LDPC_INLINE -> int {
         constexpr int B = decltype(B_)::value, S = decltype(S_)::value;
         constexpr Block blk = P.blk[B];
-        constexpr int bias = lds_bias(P, B, BLK_BYTES);
+        constexpr int bias = INPLACE ? exch_slot(P, B) * BLK_BYTES : lds_bias(P, B, BLK_BYTES);
         if constexpr (blk.kind == BLK_I) {
             return ((tb + (S * NT + blk.val) * SZ) & (M * SZ - 1)) | bias;
         } else if constexpr (QUARTER_LITERAL) {
@@ -590,6 +597,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     R v[IPT][NB];                 // variable -> check message per edge        (decoder.rs:376)
     R va[IPT][NCOLS];             // marginals                                  (decoder.rs:377)
     R llr[IPT][NTX];              // channel LLRs, read from HBM once
+    // f64 in-place mode: across iterations only the sign and the zero-ness of v matter (decoder.rs:422;
+    // the magnitudes are consumed inside the check row), so v is two bit masks instead of 2 x 30 VGPRs
+    constexpr bool VFLAGS = INPLACE && sizeof(R) == 8 && IPT * NB <= 64;
+    using FW = std::conditional_t<(IPT * NB <= 32), unsigned, unsigned long long>;
+    FW vneg = 0, vnz = 0;         // bit S*NB+B: v of that edge is negative / non-zero
 
     // Asynchronous global -> LDS copy of codeword `c`'s LLRs into the staging buffer.  Each wave
     // stages exactly the elements its own lanes will read back, so only the issuing wave's
@@ -646,9 +658,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int B = decltype(B_)::value;
                 u[S][B] = O::zero();                                               // decoder.rs:374
                 v[S][B] = O::zero();
+                vneg = 0; vnz = 0;
                 constexpr int slot = exch_slot(P, B);
                 if constexpr (slot >= 0) {
-                    constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                    constexpr int off = INPLACE ? 0 : lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                     lds_store(off + wire(B_, S_, tb), O::store(O::zero()));
                 }
             });
@@ -664,12 +677,22 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;      // split-barrier arrival counter
     };
 
+    // bit pattern (sign in bit 31) of the marginal of variable (S, C) of this thread
+    auto marginal_bits = [&](auto S_, auto C_) LDPC_INLINE -> int {
+        constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
+        constexpr int cs = col_slot(P, C);
+        if constexpr (INPLACE && cs >= 0) return *reinterpret_cast<const int *>(gbase + hi_off(cs) + (S * NT + t) * 4);
+        else return O::bits(va[S][C]);
+    };
+
     // One iteration of message passing for this thread's indices: the two phases below.
     auto variable_phase = [&]() LDPC_INLINE {
         // marginals (decoder.rs:382-383, :408)
+        int tv = t;
+        if constexpr (INPLACE) asm volatile("" : "+v"(tv));     // keep the (large-offset) LDS addresses out of loop-carried VGPRs
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             constexpr int S = decltype(S_)::value;
-            const int i = S * NT + t;
+            const int i = S * NT + tv;
             if constexpr (S == 0) LDPC_SETPRIO(LDPC_PRIO_VAR);
             else if constexpr (S == IPT / 2) LDPC_SETPRIO(0);
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
@@ -679,6 +702,30 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     if constexpr (LEAN) acc = O::load((llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(C * M) + (unsigned)i]);
                     else acc = llr[S][C];
                 }
+                if constexpr (INPLACE) {
+                    R ue[NB];                                   // the u of this column's edges, in list order
+                    static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                        constexpr int B = decltype(B_)::value;
+                        if constexpr (P.blk[B].col == C) {
+                            constexpr int slot = exch_slot(P, B);
+                            if constexpr (slot >= 0) ue[B] = O::from_lds(lds_load(slot * BLK_BYTES + i * SZ));
+                            else ue[B] = u[S][B];
+                            acc = O::add(acc, ue[B]);                                  // :408
+                        }
+                    });
+                    if constexpr (col_slot(P, C) < 0) va[S][C] = acc;               // exchanged columns: only the sign word is kept (hi array)
+                    static_for<0, NB>([&](auto B_) LDPC_INLINE {                       // nv = va - u (:421), in place
+                        constexpr int B = decltype(B_)::value;
+                        if constexpr (P.blk[B].col == C) {
+                            constexpr int slot = exch_slot(P, B);
+                            const R nv = O::sub(acc, ue[B]);
+                            if constexpr (slot >= 0) lds_store(slot * BLK_BYTES + i * SZ, O::store(nv));
+                            else u[S][B] = nv;
+                        }
+                    });
+                    constexpr int cs = col_slot(P, C);
+                    if constexpr (cs >= 0) *reinterpret_cast<int *>(gbase + hi_off(cs) + i * 4) = O::bits(acc);
+                } else {
                 static_for<0, NB>([&](auto B_) LDPC_INLINE {
                     constexpr int B = decltype(B_)::value;
                     if constexpr (P.blk[B].col == C) {
@@ -696,6 +743,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     constexpr int off = lds_xva_off(P, cs, BLK_BYTES);
                     if constexpr (ADDTID) lds_store_own(IC<off + S * NT * SZ>{}, O::store(acc));
                     else lds_store(off + i * SZ, O::store(acc));
+                }
                 }
             });
         });
@@ -877,6 +925,72 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (par_any < 0) flag_at(it) = 1;
     };
 
+    // In-place check phase (LEAN == 2): as the lean one, but an exchanged edge's slot already holds
+    // nv = va - u (written by the variable thread), its marginal's sign word comes from the hi array,
+    // and a local edge's u register holds its nv.
+    auto check_phase_inplace = [&](uint32_t it) LDPC_INLINE {
+        int par_any = 0;
+        int tb = t * SZ;
+        asm volatile("" : "+v"(tb));
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value;
+            static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
+                constexpr int Rw = decltype(R_)::value;
+                constexpr int D = row_degree(P, Rw);
+                constexpr int CH = 6, NCH = (D + CH - 1) / CH;
+                int par = 0, sgn = 0;
+                R a[D], e[D];                                   // this row's new v, its exclusive minima
+                static_for<0, NCH>([&](auto K_) LDPC_INLINE {
+                    constexpr int J0 = decltype(K_)::value * CH, J1 = J0 + CH < D ? J0 + CH : D;
+                    R nr[CH];
+                    int xw[CH];
+                    static_for<J0, J1>([&](auto J_) LDPC_INLINE {
+                        constexpr int J = decltype(J_)::value;
+                        constexpr int B = row_block(P, Rw, J);
+                        constexpr int slot = exch_slot(P, B);
+                        if constexpr (slot >= 0) {
+                            constexpr int cs = col_slot(P, P.blk[B].col);
+                            const int adr = wire(IC<B>{}, S_, tb);                     // slot base + 8 * position
+                            nr[J - J0] = O::from_lds(lds_load(adr));
+                            xw[J - J0] = *reinterpret_cast<const int *>(gbase + hi_off(cs) + (adr - slot * BLK_BYTES) / (SZ / 4));
+                        } else {
+                            nr[J - J0] = u[S][B];
+                            xw[J - J0] = marginal_bits(S_, IC<P.blk[B].col>{});
+                        }
+                    });
+                    static_for<J0, J1>([&](auto J_) LDPC_INLINE {
+                        constexpr int J = decltype(J_)::value;
+                        constexpr int B = row_block(P, Rw, J);
+                        if constexpr (VFLAGS) {
+                            constexpr FW bit = (FW)1 << (S * NB + B);
+                            const R nv = nr[J - J0];
+                            const bool drop = (vnz & bit) && ((nv < O::zero()) != ((vneg & bit) != 0));   // :422
+                            const R nw = drop ? O::zero() : nv;
+                            vneg = nw < O::zero() ? (vneg | bit) : (vneg & ~bit);
+                            vnz = nw != O::zero() ? (vnz | bit) : (vnz & ~bit);
+                            a[J] = nw;
+                        } else {
+                            v[S][B] = O::template self_correct<G == 1>(nr[J - J0], v[S][B]);   // :422-425
+                            a[J] = v[S][B];
+                        }
+                        par ^= xw[J - J0];                                             // :445-447
+                        sgn ^= O::bits(a[J]) & (int)0x80000000;                        // :439-441
+                    });
+                });
+                exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
+                static_for<0, D>([&](auto J_) LDPC_INLINE {
+                    constexpr int J = decltype(J_)::value;
+                    constexpr int B = row_block(P, Rw, J);
+                    const R un = O::apply_sign(e[J], sgn, O::bits(a[J]) & (int)0x80000000);      // :398-405
+                    if constexpr (exch_slot(P, B) >= 0) lds_store(wire(IC<B>{}, S_, tb), O::store(un));
+                    else u[S][B] = un;
+                });
+                par_any |= par;
+            });
+        });
+        if (par_any < 0) flag_at(it) = 1;
+    };
+
     if (blockIdx.x < n_groups) fetch_llrs(G == 1 ? blockIdx.x : blockIdx.x * G + grp);
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
@@ -913,7 +1027,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             LDPC_SYNC();
         }
         if (it > 0 && t == 0) flag_at(it - 1) = 0;
-        if (G == 1 || !done) { if constexpr (LEAN) check_phase_lean(it); else check_phase(it); }
+        if (G == 1 || !done) {
+            if constexpr (LEAN == 2) check_phase_inplace(it);
+            else if constexpr (LEAN == 1) check_phase_lean(it);
+            else check_phase(it);
+        }
     }
 
     if constexpr (!PF && LDPC_EARLY_FETCH) {
@@ -927,7 +1045,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
-                const unsigned long long bits = __ballot(O::bits(va[S][C]) < 0);   // bit l = lane l
+                const unsigned long long bits = __ballot(marginal_bits(S_, C_) < 0);   // bit l = lane l
                 const unsigned lo = __builtin_bswap32(__builtin_bitreverse32((unsigned)bits));
                 const unsigned hi = __builtin_bswap32(__builtin_bitreverse32((unsigned)(bits >> 32)));
                 w[S][C] = (unsigned long long)lo | ((unsigned long long)hi << 32);
@@ -946,7 +1064,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
-                const unsigned long long bits = __ballot(O::bits(va[S][C]) < 0);
+                const unsigned long long bits = __ballot(marginal_bits(S_, C_) < 0);
                 const unsigned b8 = (unsigned)(bits >> (tid & 56)) & 0xFFu;
                 if ((tid & 7) == 0 && live)
                     output[(size_t)cw * GEO::OUT_LEN + (C * M + S * NT + t) / 8] = (uint8_t)(__builtin_bitreverse32(b8) >> 24);
@@ -964,16 +1082,38 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 // LEAN: register-lean variant for the high-degree rate-4/5 codes (39 edges per index): the u of
 // the exchanged edges is re-read from LDS in the check phase instead of being kept in VGPRs and
 // the LLRs are re-read from global memory (L2) every iteration; this brings TM5120 under 128
-// VGPRs so that two workgroups share a CU.
-template <int CODE, class T, int IPT, bool PF, bool LEAN>
-__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (LEAN && sizeof(T) <= 4 ? 4 : 1))
+// VGPRs so that two workgroups share a CU.  LEAN == 2 ("in place"): additionally the variable thread
+// overwrites each exchanged u with nv = va - u in its LDS slot and publishes only the sign word of the
+// marginals, so that no array of marginals is needed -- f64 TM8192 then fits the LDS (152 KB).
+#ifndef LDPC_TM2048_WAVES
+#define LDPC_TM2048_WAVES 6
+#endif
+// Waves per SIMD the register allocation must leave room for.  The lean variant exists to reach 4
+// (two 512-thread workgroups per CU); TM2048 sits right at the 80-VGPR step between 6 and 5 waves
+// (f32 73, i8/i16 81 VGPRs: three workgroups per CU instead of two, 35 vs 30 M codewords/s for i8).
+template <int CODE, class T, int IPT, int LEAN>
+constexpr int min_waves_per_simd()
+{
+    if (sizeof(T) > 4) return 1;
+    if (LEAN == 1) return 4;
+    if (CODE == TM2048 && IPT == 1) return LDPC_TM2048_WAVES;
+    if (CODE == TM1280 && IPT == 1) return 3;         // 183 -> 168 VGPRs: f32 28.4 -> 38.6, i8 27.0 -> 34.4 M codewords/s
+#ifdef LDPC_MINW_CODE
+    if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
+#endif
+    return 1;
+}
+
+template <int CODE, class T, int IPT, bool PF, int LEAN>
+__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                  uint32_t batch, uint32_t maxiters)
 {
     using GEO = Geometry<CODE, T, IPT>;
     constexpr int Q = GEO::M / 4;
-    constexpr int GROUP_BYTES = ((GEO::NX + GEO::NXC) * GEO::M * (int)sizeof(typename Ops<T>::E) + 8 + 15) / 16 * 16;
+    constexpr int ESZ = (int)sizeof(typename Ops<T>::E);
+    constexpr int GROUP_BYTES = ((LEAN == 2 ? GEO::NX * GEO::M * ESZ + GEO::NXC * GEO::M * 4 : (GEO::NX + GEO::NXC) * GEO::M * ESZ) + 8 + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) char lds[GEO::G * GROUP_BYTES];
     __shared__ __attribute__((aligned(16))) char stage[PF ? CODES[CODE].n * sizeof(T) : 16];
     // Waves of a workgroup whose threads own two quarters' worth of indices (TM8192: 1024 threads,

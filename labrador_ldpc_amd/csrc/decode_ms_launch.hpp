@@ -19,7 +19,7 @@ hipError_t launch_decode_ms(int code, int variant, const T *llrs, uint8_t *outpu
                             uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
 
 // Resident workgroups per device for one instantiation (occupancy x compute units), cached.
-template <int CODE, class T, int IPT, bool PF, bool LEAN>
+template <int CODE, class T, int IPT, bool PF, int LEAN>
 int resident_workgroups()
 {
     using GEO = Geometry<CODE, T, IPT>;
@@ -36,8 +36,8 @@ int resident_workgroups()
     return cached[dev];
 }
 
-// Launch one instantiation (IPT indices per thread, LEAN = register-lean check phase).
-template <int CODE, class T, int IPT, bool LEAN>
+// Launch one instantiation (IPT indices per thread; LEAN 1 = register-lean check phase, 2 = in-place messages).
+template <int CODE, class T, int IPT, int LEAN>
 hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
                       size_t batch, uint32_t maxiters, hipStream_t stream)
 {
@@ -69,7 +69,7 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
     // is TM5120 only (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB).  Measured slower
     // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
-    constexpr bool LEAN = CODE == TM5120 && IPT == 1;
+    constexpr int LEAN = CODE == TM5120 && IPT == 1 ? 1 : 0;
     return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream);
 }
 

@@ -127,14 +127,15 @@ def test_f64_corner_values(code):
     _compare(code, llrs, 20)
 
 
-F64_VARIANTS = [(LDPCCode.TC128, 17), (LDPCCode.TC256, 17), (LDPCCode.TC512, 17), (LDPCCode.TM1280, 17), (LDPCCode.TM1536, 17),
-                (LDPCCode.TM2048, 1), (LDPCCode.TM5120, 18), (LDPCCode.TM6144, 18), (LDPCCode.TM6144, 2)]
+F64_VARIANTS = [(LDPCCode.TC128, 17), (LDPCCode.TC256, 17), (LDPCCode.TC512, 17), (LDPCCode.TM1280, 17), (LDPCCode.TM1280, 33),
+                (LDPCCode.TM1536, 17), (LDPCCode.TM2048, 1), (LDPCCode.TM2048, 33), (LDPCCode.TM5120, 18), (LDPCCode.TM5120, 33),
+                (LDPCCode.TM6144, 17), (LDPCCode.TM6144, 18), (LDPCCode.TM6144, 2), (LDPCCode.TM8192, 36)]
 
 
 @pytest.mark.parametrize("code,variant", F64_VARIANTS + [(c, 100) for c in ALL], ids=lambda v: getattr(v, "name", str(v)))
 def test_f64_variants(code, variant):
     """f64: the non-default register-kernel instantiations (IPT = variant & 15, register-lean check phase if
-    variant & 16) and the workspace kernel (variant 100) all agree with the oracle."""
+    variant & 16, in-place messages if variant & 32) and the workspace kernel (variant 100) all agree with the oracle."""
     rng = np.random.default_rng(41 + int(code))
     llrs, _ = oracle.awgn_llrs(code, rng, 48, 2.5, np.float64)
     llrs[0, ::5] = -0.0

@@ -6,7 +6,7 @@ from labrador_ldpc_amd import LDPCCode, LdpcHipError
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(3)
 CASES = {"TC128": (5.0, 262144), "TC256": (5.0, 262144), "TC512": (5.0, 131072), "TM1280": (4.0, 65536), "TM1536": (3.0, 65536),
-         "TM2048": (3.0, 32768), "TM5120": (4.0, 16384), "TM6144": (3.0, 16384), "TM8192": (2.0, 8192)}
+         "TM2048": (3.0, 32768), "TM5120": (4.0, 16384), "TM6144": (3.0, 16384), "TM8192": (2.0, 16384)}
 for name, (eb, frames) in CASES.items():
     code = LDPCCode[name]
     data = rng.integers(0, 256, size=(256, code.k() // 8), dtype=np.uint8)
@@ -15,7 +15,7 @@ for name, (eb, frames) in CASES.items():
     f64 = code.awgn_frames(cws, frames, sigma, seed=5, dtype="f32").double()
     ref = None
     line = [f"{name} @{eb} dB {frames} frames:"]
-    for variant in (100, 1, 17, 2, 18, 0):
+    for variant in (100, 1, 17, 2, 18, 33, 34, 36, 0):
         try:
             out = code.decode_ms_batch(f64, 25, variant=variant); torch.cuda.synchronize()
         except LdpcHipError:
