@@ -22,19 +22,24 @@ def regs(r):
                 t=[base + 36 + k for k in range(4)])
 
 
+MASK_T = "s20"            # operand holding 0x80000000 in the self-correction bit op
+MASK_AND = "0x80000000"   # ... and in the sign extraction
+CAP = "s21"               # FLT_MAX cap of the exclusive minimum
+
+
 def ops_row(r):
     R = regs(r)
     sub = [f"v_sub_f32 v{R['n'][k]}, v{R['x'][k]}, v{R['u'][k]}" for k in range(D)]
-    tt = [f"v_bitop3_b32 v{R['v'][k]}, v{R['v'][k]}, v{R['n'][k]}, s20 bitop3:0x78" for k in range(D)]
+    tt = [f"v_bitop3_b32 v{R['v'][k]}, v{R['v'][k]}, v{R['n'][k]}, {MASK_T} bitop3:0x78" for k in range(D)]
     cmp_ = [f"v_cmp_ngt_f32 vcc, 0, v{R['v'][k]}" for k in range(D)]
     cnd = [f"v_cndmask_b32 v{R['v'][k]}, 0, v{R['n'][k]}, vcc" for k in range(D)]
-    and_ = [f"v_and_b32 v{R['s'][k]}, 0x80000000, v{R['v'][k]}" for k in range(D)]
+    and_ = [f"v_and_b32 v{R['s'][k]}, {MASK_AND}, v{R['v'][k]}" for k in range(D)]
     xor3 = [f"v_bitop3_b32 v{R['t'][0]}, v{R['s'][0]}, v{R['s'][1]}, v{R['s'][2]} bitop3:0x96",
             f"v_bitop3_b32 v{R['t'][0]}, v{R['t'][0]}, v{R['s'][3]}, v{R['s'][4]} bitop3:0x96",
             f"v_xor_b32 v{R['t'][0]}, v{R['t'][0]}, v{R['s'][5]}"]
     v = R['v']
     min3 = [f"v_min3_f32 v{R['t'][1]}, |v{v[0]}|, |v{v[1]}|, |v{v[2]}|", f"v_min3_f32 v{R['t'][2]}, |v{v[3]}|, |v{v[4]}|, |v{v[5]}|",
-            f"v_min_f32 v{R['t'][3]}, s21, v{R['t'][2]}"] + \
+            f"v_min_f32 v{R['t'][3]}, {CAP}, v{R['t'][2]}"] + \
            [f"v_min3_f32 v{R['e'][k]}, |v{v[(k + 1) % 3]}|, |v{v[(k + 2) % 3]}|, v{R['t'][3]}" for k in range(3)] + \
            [f"v_min3_f32 v{R['e'][3 + k]}, |v{v[3 + (k + 1) % 3]}|, |v{v[3 + (k + 2) % 3]}|, v{R['t'][1]}" for k in range(3)]
     app = [f"v_bitop3_b32 v{R['u'][k]}, v{R['e'][k]}, v{R['t'][0]}, v{R['s'][k]} bitop3:0x96" for k in range(D)]
@@ -221,13 +226,19 @@ template <int KIND>
 __global__ void __launch_bounds__(1024) spin(float *out, int loops)
 {
     // registers v8..v167 are used by the blocks below; seed them with finite, distinct values
-    asm volatile("v_cvt_f32_u32 v1, v0\n s_mov_b32 s20, 0x80000000\n s_mov_b32 s21, 0x7f7fffff" ::: "v1", "s20", "s21");''')
+    asm volatile("v_cvt_f32_u32 v1, v0\n s_mov_b32 s20, 0x80000000\n s_mov_b32 s21, 0x7f7fffff\n v_mov_b32 v2, 0x80000000\n v_mov_b32 v3, 0x7f7fffff" ::: "v1", "v2", "v3", "s20", "s21");''')
 for v in range(8, 8 + ROWS * 40):
     print(f'    asm volatile("v_add_f32 v{v}, {float(v % 7) - 3.0}, v1" ::: "v{v}");')
 print("    for (int l = 0; l < loops; ++l) {")
 clob = ", ".join(f'"v{v}"' for v in range(8, 8 + ROWS * 40))
+VARIANTS = []
+for name, fn in ORDERS[:1] + ORDERS[4:5] + ORDERS[7:8]:
+    VARIANTS.append((name + " [M: SGPR / literal]", fn, "s20", "0x80000000", "s21"))
+    VARIANTS.append((name + " [M, cap in VGPRs]", fn, "v2", "v2", "v3"))
+    VARIANTS.append((name + " [M in a VGPR, cap SGPR]", fn, "v2", "v2", "s21"))
 nvalu = None
-for kind, (name, fn) in enumerate(ORDERS):
+for kind, (name, fn, mt, ma, cap) in enumerate(VARIANTS):
+    MASK_T, MASK_AND, CAP = mt, ma, cap
     seq = fn(list(range(ROWS)))
     valu = sum(1 for x in seq if x.startswith("v_"))
     nvalu = valu if nvalu is None else nvalu
@@ -252,13 +263,13 @@ template <int KIND> void run(const char *name, int valu)
     (void)hipEventRecord(b); (void)hipEventSynchronize(b);
     float ms; (void)hipEventElapsedTime(&ms, a, b);
     const double waves_per_simd = g_threads / 256.0;
-    printf("%-46s %7.1f ns per check row per SIMD, %.3f ns per VALU instruction per SIMD\n", name,
+    printf("%-70s %7.1f ns per check row per SIMD, %.3f ns per VALU instruction per SIMD\n", name,
            ms * 1e6 / ((double)loops * @ROWS@ * waves_per_simd), ms * 1e6 / ((double)loops * valu * waves_per_simd));
 }
 int main(int argc, char **argv)
 {
     if (argc > 1) g_threads = atoi(argv[1]);
     printf("%d threads per workgroup, one workgroup per CU; %d VALU instructions per check row of degree 6\n", g_threads, @PERROW@);'''.replace("@ROWS@", str(ROWS)).replace("@PERROW@", str(nvalu // ROWS)))
-for kind, (name, fn) in enumerate(ORDERS):
+for kind, (name, fn, mt, ma, cap) in enumerate(VARIANTS):
     print(f'    run<{kind}>("{name}", {nvalu});')
 print("    return 0;\n}")
