@@ -798,6 +798,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
         });
         __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
+#ifdef LDPC_PRIO_LOCAL
+        LDPC_SETPRIO(LDPC_PRIO_LOCAL);
+#endif
         if constexpr (!SPLIT) {
             check_local();                                                             // (2)
             __builtin_amdgcn_sched_barrier(0);
