@@ -8,6 +8,7 @@
 #include <cstdint>
 
 #include "decode_ms_kernel.hpp"
+#include "decode_ms_pair.hpp"
 
 namespace ldpc {
 
@@ -71,6 +72,31 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
     constexpr int LEAN = CODE == TM5120 && IPT == 1 ? 1 : 0;
     return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream);
+}
+
+// Pair-ownership kernel (decode_ms_pair.hpp): one workgroup per CU-resident codeword, persistent.
+constexpr int VARIANT_PAIR = 32;
+template <int CODE, class T>
+hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                       size_t batch, uint32_t maxiters, hipStream_t stream)
+{
+    using GEO = PairGeometry<CODE, T>;
+    if (batch == 0) return hipSuccess;
+    if (batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_pair_kernel<CODE, T>, GEO::NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached[dev] = per_cu * cus;
+    }
+    size_t grid = cached[dev] <= 256 ? (size_t)cached[dev] : (size_t)cached[dev] * 16;
+    if (grid > batch) grid = batch;
+    hipLaunchKernelGGL((decode_ms_pair_kernel<CODE, T>), dim3((unsigned)grid), dim3(GEO::NT), 0, stream,
+                       llrs, output, iters, success, (uint32_t)batch, maxiters);
+    return hipGetLastError();
 }
 
 // one `case` of the dispatch switch: default IPT plus optional alternatives

@@ -104,11 +104,24 @@ def test_empty_batch():
     assert out.shape == (0, code.output_len()) and it.shape == (0,) and ok.shape == (0,)
 
 
-@pytest.mark.parametrize("code,variant", [(LDPCCode.TM8192, 4), (LDPCCode.TM2048, 2), (LDPCCode.TM1536, 2), (LDPCCode.TM6144, 2)],
-                         ids=["TM8192-ipt4", "TM2048-ipt2", "TM1536-ipt2", "TM6144-ipt2"])
+@pytest.mark.parametrize("code,variant", [(LDPCCode.TM8192, 2), (LDPCCode.TM8192, 4), (LDPCCode.TM8192, 32), (LDPCCode.TM2048, 2),
+                                          (LDPCCode.TM2048, 32), (LDPCCode.TM1536, 2), (LDPCCode.TM6144, 2), (LDPCCode.TM6144, 32)],
+                         ids=["TM8192-ipt2", "TM8192-ipt4", "TM8192-pair", "TM2048-ipt2", "TM2048-pair", "TM1536-ipt2", "TM6144-ipt2", "TM6144-pair"])
 def test_variants(code, variant):
+    """Non-default kernels: (t, t + M/2) ownership with 2 or 4 indices per thread, pair ownership (2t, 2t + 1) = 32."""
     rng = np.random.default_rng(21)
-    llrs, _ = oracle.awgn_llrs(code, rng, 64, 2.0, np.float32)
+    llrs, _ = oracle.awgn_llrs(code, rng, 96, 2.0, np.float32)
+    llrs[0, ::7] = -0.0
+    llrs[1] *= np.float32(1e37)
+    _compare(code, llrs, 25, variant=variant)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16], ids=["i8", "i16"])
+@pytest.mark.parametrize("variant", [2, 32])
+def test_tm8192_integer_variants(dtype, variant):
+    code = LDPCCode.TM8192
+    rng = np.random.default_rng(23)
+    llrs, _ = oracle.awgn_llrs(code, rng, 96, 2.5, dtype, scale=8.0 if dtype == np.int8 else 64.0, lim=31 if dtype == np.int8 else 4095)
     _compare(code, llrs, 25, variant=variant)
 
 

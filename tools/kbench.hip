@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <vector>
 #include "decode_ms_kernel.hpp"
+#include "decode_ms_pair.hpp"
 #include "channel.hpp"
 #ifndef KCODE
 #define KCODE 8
@@ -22,6 +23,9 @@
 #endif
 #ifndef KLEAN
 #define KLEAN false
+#endif
+#ifndef KPAIR
+#define KPAIR 0
 #endif
 #ifndef KPF
 #define KPF false
@@ -53,7 +57,11 @@ int main()
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
+#if KPAIR
+        hipLaunchKernelGGL((decode_ms_pair_kernel<code, KT>), dim3(groups), dim3(PairGeometry<code, KT>::NT), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
+#else
         hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT);
+#endif
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep > 0 && ms < best) best = ms;
@@ -64,7 +72,7 @@ int main()
     double si = 0, sk = 0; unsigned long long h = 1469598103934665603ull;
     for (size_t f = 0; f < F; ++f) { si += hi[f]; sk += hk[f]; h = (h ^ hi[f] ^ ((unsigned long long)hk[f] << 32)) * 1099511628211ull; }
     for (size_t i = 0; i < F * ol; ++i) h = (h ^ ho[i]) * 1099511628211ull;
-    printf("code %d T%zu ipt %d pf %d grid %u frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", code, sizeof(KT), KIPT, (int)KPF, groups, F, best,
+    printf("%scode %d T%zu ipt %d pf %d grid %u frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", KPAIR ? "PAIR " : "", code, sizeof(KT), KIPT, (int)KPF, groups, F, best,
            F / best / 1e3, si / F, sk / F, h);
     return 0;
 }
