@@ -168,7 +168,7 @@ def main():
                        "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "decode_ms_kernel", "kernel_ms": kernel_ms_max,
+                         "kernel": ("decode_ms_pair_kernel" if (args.code == "TM8192" and args.dtype != "f64" and args.variant in (0, 32)) else "decode_ms_kernel"), "kernel_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "valu_issue": valu,
             "diag": {"mean_iters_returned": mean_iters, "frame_failure_rate": frame_fail,

@@ -22,6 +22,13 @@
 
 #include "decode_ms_kernel.hpp"
 
+// Experiment switch: re-read the LLRs from L2 every iteration instead of holding them in 8 VGPRs.
+#ifndef LDPC_PAIR_RELOAD_LLR
+#define LDPC_PAIR_RELOAD_LLR 0
+#endif
+#ifndef LDPC_PAIR_ODD_B64
+#define LDPC_PAIR_ODD_B64 -1      // -1 = per type (see ODD_B64), 0 / 1 = force
+#endif
 #ifndef LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}   // wave priority over the six (check row, index) steps, see LDPC_PRIO
 #endif
@@ -63,6 +70,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     constexpr int N = CODES[CODE].n, NTX = N / M, NX = GEO::NX, NXC = GEO::NXC;
     constexpr int Q = M / 4, IPT = 2;
     constexpr int BLK_BYTES = M * 4, FLAG_OFF = (NX + NXC) * BLK_BYTES;
+    // odd rotations read their two marginals as halves of two aligned 64-bit pairs (see check_phase): +12 % for
+    // i8 (8.0 -> 9.0 M codewords/s), but the wider destinations cost f32 nine spilled VGPRs (6.7 -> 6.5)
+    constexpr bool ODD_B64 = LDPC_PAIR_ODD_B64 >= 0 ? LDPC_PAIR_ODD_B64 != 0 : !std::is_same_v<T, float>;
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
 
@@ -134,7 +144,15 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             constexpr int C = decltype(C_)::value;
             if constexpr (C == NCOLS / 2) LDPC_SETPRIO(0);
             R acc0 = O::zero(), acc1 = O::zero();
-            if constexpr (C < NTX) { acc0 = llr[0][C]; acc1 = llr[1][C]; }
+            if constexpr (C < NTX) {
+#if LDPC_PAIR_RELOAD_LLR
+                const T *src = (llrs + (size_t)cw * N) + (unsigned)(C * M);
+                acc0 = O::load(src[2 * (unsigned)tq]);
+                acc1 = O::load(src[2 * (unsigned)tq + 1]);
+#else
+                acc0 = llr[0][C]; acc1 = llr[1][C];
+#endif
+            }
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int B = decltype(B_)::value;
                 if constexpr (P.blk[B].col == C) {
@@ -177,12 +195,22 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             if constexpr (slot >= 0) {
                 constexpr int cs = col_slot(P, P.blk[B].col);
                 constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
-                ad[0][B] = wire(B_, IC<0>{}, tb8);
                 if constexpr (even_c(B)) {
+                    ad[0][B] = wire(B_, IC<0>{}, tb8);
                     const ldpc_f2 xp = lds2(off + ad[0][B]);
                     xs[0][B] = O::from_lds(xp.x);
                     xs[1][B] = O::from_lds(xp.y);
+                } else if constexpr (ODD_B64) {
+                    // odd phi: the two marginals are the HIGH half of one aligned pair and the LOW half of the next.
+                    // Two ds_read_b64 of those pairs (2 LDS cycles each, conflict-free) instead of two
+                    // ds_read_b32 whose 8-byte lane stride is a 2-way bank conflict (4 cycles each).
+                    ad[0][B] = wire(B_, IC<-1>{}, tb8);                 // aligned pair (2t + phi - 1, 2t + phi)
+                    ad[1][B] = wire(B_, IC<1>{}, tb8);                  // aligned pair (2t + phi + 1, 2t + phi + 2), wraps with the quarter
+                    const ldpc_f2 lo = lds2(off + ad[0][B]), hi = lds2(off + ad[1][B]);
+                    xs[0][B] = O::from_lds(lo.y);
+                    xs[1][B] = O::from_lds(hi.x);
                 } else {
+                    ad[0][B] = wire(B_, IC<0>{}, tb8);
                     ad[1][B] = wire(B_, IC<1>{}, tb8);
                     xs[0][B] = O::from_lds(lds1(off + ad[0][B]));
                     xs[1][B] = O::from_lds(lds1(off + ad[1][B]));
@@ -234,7 +262,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                     constexpr int slot = exch_slot(P, B);
                     if constexpr (slot >= 0) {
                         constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
-                        if constexpr (!even_c(B)) lds1(off + ad[S][B]) = O::store(u[S][B]);
+                        if constexpr (!even_c(B)) lds1(off + ad[S][B] + (ODD_B64 && S == 0 ? 4 : 0)) = O::store(u[S][B]);
                         else if constexpr (S == 1) lds2(off + ad[0][B]) = ldpc_f2{O::store(u[0][B]), O::store(u[1][B])};
                     }
                 });

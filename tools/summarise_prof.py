@@ -14,7 +14,7 @@ for i in range(1, 6):
         shutil.copy(f, f"{dst}/pmc{i}_counters.csv")
         acc = {}
         for r in csv.DictReader(open(f)):
-            if "decode_ms_kernel" not in r["Kernel_Name"]:
+            if "decode_ms_" not in r["Kernel_Name"]:
                 continue
             acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
