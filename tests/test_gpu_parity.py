@@ -160,3 +160,16 @@ def test_f64_unbuilt_variant_is_reported():
     code = LDPCCode.TM8192
     with pytest.raises(la.LdpcHipError, match="variant"):
         code.decode_ms_batch(np.zeros((2, code.n()), dtype=np.float64), 5, variant=1)   # 176 KB of LDS: not built
+
+
+def test_tm8192_ragged_batches_on_the_pair_kernel():
+    """Batch sizes around the persistent grid (256 workgroups on an MI355X): 1 frame, fewer frames than
+    workgroups, one and a few more than the grid, so that workgroups decode 0, 1 or 2 codewords."""
+    code = LDPCCode.TM8192
+    rng = np.random.default_rng(77)
+    base, _ = oracle.awgn_llrs(code, rng, 24, 1.6, np.float32)
+    ref = oracle.decode_ms_batch(code, base, 25)
+    for b in (1, 2, 255, 257, 300, 520):
+        idx = np.arange(b) % len(base)
+        out, it, ok = code.decode_ms_batch(base[idx], 25)
+        assert (out == ref[0][idx]).all() and (it == ref[1][idx]).all() and (ok == ref[2][idx]).all(), b
