@@ -29,6 +29,10 @@
 #ifndef LDPC_PAIR_ODD_B64
 #define LDPC_PAIR_ODD_B64 -1      // -1 = per type (see ODD_B64), 0 / 1 = force
 #endif
+// Experiment switch: request the marginals of the odd rotations after the local-edge work instead of first.
+#ifndef LDPC_PAIR_LATE_ODD
+#define LDPC_PAIR_LATE_ODD 0
+#endif
 #ifndef LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}   // wave priority over the six (check row, index) steps, see LDPC_PRIO
 #endif
@@ -189,10 +193,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         LDPC_SETPRIO(3);
         R xs[IPT][NB];
         int ad[IPT][NB];
-        static_for<0, NB>([&](auto B_) LDPC_INLINE {                                   // (1) request the exchanged marginals
+        auto request = [&](auto ODD_) LDPC_INLINE {                                    // (1) request the exchanged marginals
+        static_for<0, NB>([&](auto B_) LDPC_INLINE {
             constexpr int B = decltype(B_)::value;
             constexpr int slot = exch_slot(P, B);
-            if constexpr (slot >= 0) {
+            constexpr int which = decltype(ODD_)::value;                              // 0 = even rotations, 1 = odd, 2 = all
+            if constexpr (slot >= 0 && (which == 2 || (which == 1) == !even_c(B))) {
                 constexpr int cs = col_slot(P, P.blk[B].col);
                 constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                 if constexpr (even_c(B)) {
@@ -217,6 +223,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 }
             }
         });
+        };
+        request(IC<LDPC_PAIR_LATE_ODD ? 0 : 2>{});
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2) local edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
@@ -224,6 +232,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col]);
             });
         });
+        if constexpr (LDPC_PAIR_LATE_ODD) request(IC<1>{});
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
