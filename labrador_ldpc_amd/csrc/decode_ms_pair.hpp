@@ -36,8 +36,28 @@
 #ifndef LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}   // wave priority over the six (check row, index) steps, see LDPC_PRIO
 #endif
+#ifndef LDPC_PAIR_HEAD_Q
+#define LDPC_PAIR_HEAD_Q {3, 3, 3, 3}      // priority of the request / edge-update stages of the check phase, per quarter
+#endif
+#ifndef LDPC_PAIR_VAR_Q
+#define LDPC_PAIR_VAR_Q {LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR}   // first half of the variable phase
+#endif
+#ifndef LDPC_PAIR_VAR2_Q
+#define LDPC_PAIR_VAR2_Q {0, 0, 0, 0}      // second half of the variable phase
+#endif
+#ifndef LDPC_PRIO_ROWS_PAIR_Q0
+#define LDPC_PRIO_ROWS_PAIR_Q0 LDPC_PRIO_ROWS_PAIR
+#define LDPC_PRIO_ROWS_PAIR_Q1 LDPC_PRIO_ROWS_PAIR
+#define LDPC_PRIO_ROWS_PAIR_Q2 LDPC_PRIO_ROWS_PAIR
+#define LDPC_PRIO_ROWS_PAIR_Q3 LDPC_PRIO_ROWS_PAIR
+#endif
 
 namespace ldpc {
+
+#ifdef LDPC_DIAG_STAMPS
+// per wave: cycles in [variable phase, wait at barrier 2, check phase, wait at barrier 1], summed over iterations
+__device__ unsigned long long g_stamps[256 * 16 * 4];
+#endif
 
 typedef float ldpc_f2 __attribute__((ext_vector_type(2)));
 
@@ -143,10 +163,13 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
-        LDPC_SETPRIO(LDPC_PRIO_VAR);
+        {
+            constexpr int var[4] = LDPC_PAIR_VAR_Q;
+            LDPC_SETPRIO(var[JW]);
+        }
         static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
             constexpr int C = decltype(C_)::value;
-            if constexpr (C == NCOLS / 2) LDPC_SETPRIO(0);
+            if constexpr (C == NCOLS / 2) { constexpr int var2[4] = LDPC_PAIR_VAR2_Q; LDPC_SETPRIO(var2[JW]); }
             R acc0 = O::zero(), acc1 = O::zero();
             if constexpr (C < NTX) {
 #if LDPC_PAIR_RELOAD_LLR
@@ -190,7 +213,10 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
-        LDPC_SETPRIO(3);
+        {
+            constexpr int head[4] = LDPC_PAIR_HEAD_Q;
+            LDPC_SETPRIO(head[JW]);
+        }
         R xs[IPT][NB];
         int ad[IPT][NB];
         auto request = [&](auto ODD_) LDPC_INLINE {                                    // (1) request the exchanged marginals
@@ -246,7 +272,10 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value;
                 {
-                    constexpr int prio_rows[6] = LDPC_PRIO_ROWS_PAIR;
+                    // one table per quarter: on every SIMD the four waves of a workgroup are one from each
+                    // quarter, oldest = quarter 0, and age is the tie-break of the issue arbitration
+                    constexpr int prio_tab[4][6] = {LDPC_PRIO_ROWS_PAIR_Q0, LDPC_PRIO_ROWS_PAIR_Q1, LDPC_PRIO_ROWS_PAIR_Q2, LDPC_PRIO_ROWS_PAIR_Q3};
+                    constexpr int prio_rows[6] = {prio_tab[JW][0], prio_tab[JW][1], prio_tab[JW][2], prio_tab[JW][3], prio_tab[JW][4], prio_tab[JW][5]};
                     constexpr int step = Rw * IPT + S, nsteps = IPT * NROWS;
                     constexpr int k = step - (nsteps - 6);
                     constexpr int now = k >= 0 ? prio_rows[k] : 3, before = (step > 0 && k >= 1) ? prio_rows[k - 1] : 3;
@@ -289,16 +318,41 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         begin_codeword();
         bool done = false, ok = false;
         uint32_t iters = maxiters;
+#ifdef LDPC_DIAG_STAMPS
+        unsigned long long acc_var = 0, acc_w2 = 0, acc_chk = 0, acc_w1 = 0, t3 = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t it = 0;; ++it) {
             LDPC_SYNC();
+#ifdef LDPC_DIAG_STAMPS
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            if (it > 0) acc_w1 += t0 - t3;
+#endif
             if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
             else if (it == maxiters) { done = true; }
             if (done) break;
             variable_phase();
+#ifdef LDPC_DIAG_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
             LDPC_SYNC();
+#ifdef LDPC_DIAG_STAMPS
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
             if (it > 0 && t == 0) flag_at(it - 1) = 0;
             check_phase(it);
+#ifdef LDPC_DIAG_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t3 = __builtin_amdgcn_s_memtime();
+            acc_var += t1 - t0; acc_w2 += t2 - t1; acc_chk += t3 - t2;
+#endif
         }
+#ifdef LDPC_DIAG_STAMPS
+        if ((t & 63) == 0 && blockIdx.x < 256) {
+            unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 4;
+            d[0] += acc_var; d[1] += acc_w2; d[2] += acc_chk; d[3] += acc_w1;
+        }
+#endif
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
         // s_bitreplicate doubles every bit), then bit-reversed per byte

@@ -72,6 +72,20 @@ int main()
     double si = 0, sk = 0; unsigned long long h = 1469598103934665603ull;
     for (size_t f = 0; f < F; ++f) { si += hi[f]; sk += hk[f]; h = (h ^ hi[f] ^ ((unsigned long long)hk[f] << 32)) * 1099511628211ull; }
     for (size_t i = 0; i < F * ol; ++i) h = (h ^ ho[i]) * 1099511628211ull;
+#ifdef LDPC_DIAG_STAMPS
+    {
+        std::vector<unsigned long long> st(256 * 16 * 4);
+        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(ldpc::g_stamps), st.size() * 8));
+        double tot[4] = {0, 0, 0, 0}, perq[4][4] = {};
+        for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) for (int k = 0; k < 4; ++k) { tot[k] += st[(b * 16 + w) * 4 + k]; perq[w / 4][k] += st[(b * 16 + w) * 4 + k]; }
+        const double iters_total = (si + F) * 5.0;     // 5 launches accumulated (1 warm + 4 timed); + F: the final verdict pass
+        printf("stamps (s_memtime ticks per wave and iteration, all launches): variable %.0f | wait2 %.0f | check %.0f | wait1 %.0f\n",
+               tot[0] / 4096 / (iters_total / 256) , tot[1] / 4096 / (iters_total / 256), tot[2] / 4096 / (iters_total / 256), tot[3] / 4096 / (iters_total / 256));
+        for (int q = 0; q < 4; ++q)
+            printf("  quarter %d waves: variable %.0f | wait2 %.0f | check %.0f | wait1 %.0f\n", q, perq[q][0] / 1024 / (iters_total / 256), perq[q][1] / 1024 / (iters_total / 256),
+                   perq[q][2] / 1024 / (iters_total / 256), perq[q][3] / 1024 / (iters_total / 256));
+    }
+#endif
     printf("%scode %d T%zu ipt %d pf %d grid %u frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", KPAIR ? "PAIR " : "", code, sizeof(KT), KIPT, (int)KPF, groups, F, best,
            F / best / 1e3, si / F, sk / F, h);
     return 0;
