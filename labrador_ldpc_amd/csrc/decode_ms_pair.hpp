@@ -36,6 +36,10 @@
 #ifndef LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}   // wave priority over the six (check row, index) steps, see LDPC_PRIO
 #endif
+// Which quarter the k-th group of waves (oldest first) works on.
+#ifndef LDPC_PAIR_QMAP
+#define LDPC_PAIR_QMAP {0, 1, 2, 3}
+#endif
 #ifndef LDPC_PAIR_HEAD_Q
 #define LDPC_PAIR_HEAD_Q {3, 3, 3, 3}      // priority of the request / edge-update stages of the check phase, per quarter
 #endif
@@ -100,7 +104,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
 
-    const int t = threadIdx.x;
+    // logical thread index: waves are handed quarters in the order LDPC_PAIR_QMAP (the kernel wrapper
+    // branches on the same map), everything below sees only t
+    constexpr int qmap[4] = LDPC_PAIR_QMAP;
+    static_assert(qmap[0] + qmap[1] + qmap[2] + qmap[3] == 6, "LDPC_PAIR_QMAP must be a permutation of 0..3");
+    const int t = (int)(threadIdx.x & (M / 8 - 1)) + JW * (M / 8);
     __builtin_assume(t >= 0 && t < NT);
     const uint32_t n_groups = batch;
     uint32_t cw = blockIdx.x;
@@ -389,7 +397,8 @@ decode_ms_pair_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output, 
 {
     using GEO = PairGeometry<CODE, T>;
     __shared__ __attribute__((aligned(16))) char lds[GEO::LDS_BYTES];
-    const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8);     // quarter of this wave's indices
+    constexpr int qmap[4] = LDPC_PAIR_QMAP;
+    const int jw = qmap[__builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8)];   // quarter of this wave's indices
     if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds);
     else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds);
     else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, lds);
