@@ -37,6 +37,11 @@
 #define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}   // wave priority over the six (check row, index) steps, see LDPC_PRIO
 #endif
 // Which quarter the k-th group of waves (oldest first) works on.
+// Issue the next codeword's LLR loads before this one's epilogue: the fixed cost per codeword drops from
+// 2.55 to 2.12 us (1.305 -> 1.086 ms per 131 072 frames at 0 iterations), +0.7 % at 25.
+#ifndef LDPC_PAIR_EARLY_FETCH
+#define LDPC_PAIR_EARLY_FETCH 1
+#endif
 #ifndef LDPC_PAIR_QMAP
 #define LDPC_PAIR_QMAP {0, 1, 2, 3}
 #endif
@@ -322,7 +327,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     if (blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
         cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+#if !LDPC_PAIR_EARLY_FETCH
         if (!first) fetch_llrs(cw);
+#else
+        (void)first;
+#endif
         begin_codeword();
         bool done = false, ok = false;
         uint32_t iters = maxiters;
@@ -360,6 +369,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 4;
             d[0] += acc_var; d[1] += acc_w2; d[2] += acc_chk; d[3] += acc_w1;
         }
+#endif
+#if LDPC_PAIR_EARLY_FETCH
+        if (g + gridDim.x < n_groups) fetch_llrs((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));   // behind the epilogue
 #endif
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
