@@ -365,16 +365,23 @@ template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
 // min1/min2 start at maxval (decoder.rs:414-415) and are only replaced by strictly smaller
 // values (:430-434), hence the clamp.  Elements are grouped in threes so that one min3 per
 // element finishes the job: ~1.7 operations per edge at degree 6, ~1.9 at degree 18.
-template <class O, int D, bool ABS>
+template <class O, int D, bool ABS, bool CAP = true>
 LDPC_DEV void exclusive_min(const typename O::R (&a)[D], typename O::R (&e)[D])
 {
+    // CAP = false: the caller guarantees that every magnitude is below maxval (then the clamp is the
+    // identity); only checks of degree >= 4 save operations by it
     using R = typename O::R;
     const R MX = O::maxval();
     if constexpr (D == 1) {
         e[0] = MX;
     } else if constexpr (D == 2) {
-        e[0] = O::template min2_cap<ABS>(a[1]);
-        e[1] = O::template min2_cap<ABS>(a[0]);
+        if constexpr (CAP) {
+            e[0] = O::template min2_cap<ABS>(a[1]);
+            e[1] = O::template min2_cap<ABS>(a[0]);
+        } else {
+            e[0] = ABS ? O::mag(a[1]) : a[1];
+            e[1] = ABS ? O::mag(a[0]) : a[0];
+        }
     } else if constexpr (D == 3) {
         e[0] = O::template min3_cap<ABS, ABS>(a[1], a[2]);
         e[1] = O::template min3_cap<ABS, ABS>(a[0], a[2]);
@@ -388,7 +395,7 @@ LDPC_DEV void exclusive_min(const typename O::R (&a)[D], typename O::R (&e)[D])
             else if constexpr (n == 2) t[g] = O::template min2<ABS, ABS>(a[3 * g], a[3 * g + 1]);
             else t[g] = ABS ? O::mag(a[3 * g]) : a[3 * g];
         });
-        exclusive_min<O, G, false>(t, x);
+        exclusive_min<O, G, false, CAP>(t, x);
         static_for<0, G>([&](auto g_) LDPC_INLINE {
             constexpr int g = decltype(g_)::value, n = (3 * g + 3 <= D) ? 3 : D - 3 * g;
             if constexpr (n == 3) {

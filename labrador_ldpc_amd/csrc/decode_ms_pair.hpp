@@ -42,6 +42,11 @@
 #ifndef LDPC_PAIR_EARLY_FETCH
 #define LDPC_PAIR_EARLY_FETCH 1
 #endif
+// f32: run the check phase without the FLT_MAX clamp of the exclusive minimum when no LLR of the codeword
+// exceeds 2^100 in magnitude (see begin_codeword).
+#ifndef LDPC_PAIR_NOCAP
+#define LDPC_PAIR_NOCAP 1
+#endif
 #ifndef LDPC_PAIR_QMAP
 #define LDPC_PAIR_QMAP {0, 1, 2, 3}
 #endif
@@ -123,6 +128,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     auto lds1 = [&](int off) LDPC_INLINE -> float & { return *reinterpret_cast<float *>(lds + off); };
     auto lds2 = [&](int off) LDPC_INLINE -> ldpc_f2 & { return *reinterpret_cast<ldpc_f2 *>(lds + off); };
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 4 * (which & 1)); };
+    auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 8); };
+    constexpr bool NOCAP_POSSIBLE = LDPC_PAIR_NOCAP && std::is_same_v<T, float>;
 
     // Rotation of block B for this body's quarter JW: phi, and where the even/odd split puts the edges.
     // Byte address (inside the block region, biased as in decode_ms_kernel.hpp) of the variable that check
@@ -169,6 +176,19 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             lds2(lds_xu_off(P, decltype(X_)::value, BLK_BYTES) + tb8) = ldpc_f2{0.0f, 0.0f};
         });
         if (t < 2) flag_at(t) = 0;
+        // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
+        // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
+        // |LLR| <= 2^100 nothing does (|va| <= 7 * 2^100), and the check phase runs without the clamp
+        // operations (8 of 76 min-class instructions per thread and iteration).
+        if constexpr (NOCAP_POSSIBLE) {
+            bool big = false;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= 0x1p100f);   // NaN counts as big
+                });
+            });
+            if (__ballot(big) != 0 && (t & 63) == 0) cap_flag() = 1;
+        }
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
@@ -221,7 +241,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- check phase (decoder.rs:414-450 and :391-405 of the next iteration) -------------------------
-    auto check_phase = [&](uint32_t it) LDPC_INLINE {
+    auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
+        constexpr bool CAP = decltype(CAP_)::value != 0;
         int par_any = 0;
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
@@ -305,7 +326,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
                 const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
-                exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
+                exclusive_min<O, D, true, CAP>(a, e);                                  // :391-395, :430-435
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
@@ -324,6 +345,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- persistent loop over codewords ----------------------------------------------------------------
+    if (t == 0) cap_flag() = 0;
+    LDPC_SYNC();
     if (blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
         cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
@@ -338,31 +361,41 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #ifdef LDPC_DIAG_STAMPS
         unsigned long long acc_var = 0, acc_w2 = 0, acc_chk = 0, acc_w1 = 0, t3 = __builtin_amdgcn_s_memtime();
 #endif
-        for (uint32_t it = 0;; ++it) {
-            LDPC_SYNC();
+        // the iterations, as one loop per clamp mode (two check phases inside ONE loop cost 330 spilled VGPRs)
+        auto iterate = [&](auto CAP_) LDPC_INLINE {
+            for (uint32_t it = 0;; ++it) {
+                if (it > 0) LDPC_SYNC();          // (the barrier before iteration 0 is taken below, before the clamp mode is read)
 #ifdef LDPC_DIAG_STAMPS
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            if (it > 0) acc_w1 += t0 - t3;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                if (it > 0) acc_w1 += t0 - t3;
 #endif
-            if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
-            else if (it == maxiters) { done = true; }
-            if (done) break;
-            variable_phase();
+                if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
+                else if (it == maxiters) { done = true; }
+                if (done) break;
+                variable_phase();
 #ifdef LDPC_DIAG_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-            LDPC_SYNC();
+                LDPC_SYNC();
 #ifdef LDPC_DIAG_STAMPS
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
-            if (it > 0 && t == 0) flag_at(it - 1) = 0;
-            check_phase(it);
+                if (it > 0 && t == 0) flag_at(it - 1) = 0;
+                check_phase(it, CAP_);
 #ifdef LDPC_DIAG_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            t3 = __builtin_amdgcn_s_memtime();
-            acc_var += t1 - t0; acc_w2 += t2 - t1; acc_chk += t3 - t2;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                t3 = __builtin_amdgcn_s_memtime();
+                acc_var += t1 - t0; acc_w2 += t2 - t1; acc_chk += t3 - t2;
 #endif
+            }
+        };
+        LDPC_SYNC();                              // the zeroed exchange slots, the flags and the clamp vote are visible
+        if constexpr (NOCAP_POSSIBLE) {
+            if (__builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
+            else iterate(IC<0>{});
+        } else {
+            iterate(IC<1>{});
         }
 #ifdef LDPC_DIAG_STAMPS
         if ((t & 63) == 0 && blockIdx.x < 256) {
@@ -397,7 +430,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 dst[1] = w[1];
             }
         });
-        if (t == 0) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
+        if (t == 0) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; cap_flag() = 0; }
         LDPC_SYNC();
     }
 }

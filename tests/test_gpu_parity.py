@@ -173,3 +173,22 @@ def test_tm8192_ragged_batches_on_the_pair_kernel():
         idx = np.arange(b) % len(base)
         out, it, ok = code.decode_ms_batch(base[idx], 25)
         assert (out == ref[0][idx]).all() and (it == ref[1][idx]).all() and (ok == ref[2][idx]).all(), b
+
+
+def test_tm8192_clamp_mode_is_chosen_per_codeword():
+    """The f32 pair kernel drops the FLT_MAX clamp of the exclusive minimum for codewords whose LLRs are all
+    <= 2^100 in magnitude and keeps it for the others; a persistent workgroup decodes both kinds back to back
+    (frames f, f + 256, f + 512 share a workgroup on an MI355X)."""
+    code = LDPCCode.TM8192
+    rng = np.random.default_rng(99)
+    base, _ = oracle.awgn_llrs(code, rng, 40, 1.8, np.float32)
+    llrs = base[np.arange(600) % 40].copy()
+    for f in range(600):
+        kind = (f // 7) % 4
+        if kind == 1:
+            llrs[f, (f * 13) % code.n()] = np.inf
+        elif kind == 2:
+            llrs[f] *= np.float32(1e37)                     # sums overflow to +-inf
+        elif kind == 3:
+            llrs[f, ::97] = np.float32(2.0 ** 100)          # the largest LLR that still takes the clamp-free path
+    _compare(code, llrs, 20)
