@@ -76,6 +76,10 @@
 // register M0 holds 16 bits, so it is only correct while the workgroup's LDS allocation starts below
 // 64 KB -- true for a lone TM8192 workgroup, false as soon as several workgroups (or another kernel)
 // share the CU (TM2048 decoded wrongly).  Off.
+// f32: clamp-free check phase for codewords whose LLRs are bounded (see NOCAP_POSSIBLE in the kernel body).
+#ifndef LDPC_NOCAP
+#define LDPC_NOCAP 1
+#endif
 #ifndef LDPC_ADDTID
 #define LDPC_ADDTID 0
 #endif
@@ -541,6 +545,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
+    // f32, one codeword per workgroup: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415)
+    // can only bite if some magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums
+    // overflow.  With every |LLR| <= 2^100 nothing does, and the check phase runs without the clamp
+    // operations (TM8192 pair kernel +3 %).  The vote is one LDS word per codeword (the split-barrier
+    // counter's, unused then).
+    // Measured: TM2048 41.3 -> 43.0 M codewords/s; TM6144 -1.6 %, TM1536 -0.7 %, TM1280 -11 %, and 34 spilled VGPRs
+    // with two indices per thread (the second copy of the loop is not free), hence TM2048 only.
+    constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && CODE == TM2048 && G == 1 && LEAN == 0 && IPT == 1 && !(LDPC_SPLIT_BARRIER);
+    auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(gbase + FLAG_OFF + 8); };
 
     // Split barrier between the variable and the check phase (single-codeword workgroups): a
     // wave ARRIVES (LDS counter) as soon as its marginals are stored, updates its local edges,
@@ -686,7 +699,17 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
         (void)tu;
         if (t < 2) flag_at(t) = 0;
-        if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;      // split-barrier arrival counter
+        if constexpr (NOCAP_POSSIBLE) {
+            bool big = false;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= 0x1p100f);   // NaN counts as big
+                });
+            });
+            if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
+        } else {
+            if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;  // split-barrier arrival counter
+        }
     };
 
     // bit pattern (sign in bit 31) of the marginal of variable (S, C) of this thread
@@ -782,7 +805,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
     };
 
-    auto check_phase = [&](uint32_t it) LDPC_INLINE {
+    auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
+        constexpr bool CAP = decltype(CAP_)::value != 0;
         // decoder.rs:414-450, and :391-405 of the NEXT iteration
         int par_any = 0;          // bit 31 set if any owned check has odd parity
         // LDS addresses of the exchanged edges are two VALU ops each from `tb`; making `tb`
@@ -849,7 +873,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 #ifdef LDPC_DIAG_NOMIN
                 static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = O::mag(a[decltype(J_)::value]); });
 #else
-                exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
+                exclusive_min<O, D, true, CAP>(a, e);                                       // :391-395, :430-435
 #endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
@@ -1006,6 +1030,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (par_any < 0) flag_at(it) = 1;
     };
 
+    if constexpr (NOCAP_POSSIBLE) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
     if (blockIdx.x < n_groups) fetch_llrs(G == 1 ? blockIdx.x : blockIdx.x * G + grp);
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
@@ -1023,8 +1048,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // simply stops updating (its lanes are masked off) until the whole wave is done.
     bool done = false, ok = false;
     uint32_t iters = maxiters;
+    // the iterations; one copy of the loop per clamp mode (two check phases inside one loop spill)
+    auto iterate = [&](auto CAP_) LDPC_INLINE {
     for (uint32_t it = 0;; ++it) {
-        LDPC_SYNC();              // u of the exchanged blocks and the parity vote are visible
+        if (it > 0) LDPC_SYNC();  // u of the exchanged blocks and the parity vote are visible (iteration 0: barrier below)
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
             if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
@@ -1045,8 +1072,16 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (G == 1 || !done) {
             if constexpr (LEAN == 2) check_phase_inplace(it);
             else if constexpr (LEAN == 1) check_phase_lean(it);
-            else check_phase(it);
+            else check_phase(it, CAP_);
         }
+    }
+    };
+    LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
+    if constexpr (NOCAP_POSSIBLE) {
+        if (__builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
+        else iterate(IC<0>{});
+    } else {
+        iterate(IC<1>{});
     }
 
     if constexpr (!PF && LDPC_EARLY_FETCH) {
@@ -1087,6 +1122,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
     }
     if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
+    if constexpr (NOCAP_POSSIBLE) { if (t == 0) cap_flag() = 0; }
     LDPC_SYNC();                  // every wave is done with the flags before the next codeword resets them
     }                             // persistent loop over codeword groups
 }

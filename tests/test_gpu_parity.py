@@ -192,3 +192,19 @@ def test_tm8192_clamp_mode_is_chosen_per_codeword():
         elif kind == 3:
             llrs[f, ::97] = np.float32(2.0 ** 100)          # the largest LLR that still takes the clamp-free path
     _compare(code, llrs, 20)
+
+
+def test_tm2048_clamp_mode_is_chosen_per_codeword():
+    """Same for the (t)-ownership kernel, which uses the clamp-free check phase on TM2048 f32; 13 000 frames
+    exceed the persistent grid (3 workgroups x 256 CUs x 16), so workgroups decode both kinds in sequence."""
+    code = LDPCCode.TM2048
+    rng = np.random.default_rng(98)
+    base, _ = oracle.awgn_llrs(code, rng, 64, 2.2, np.float32)
+    llrs = base[np.arange(13000) % 64].copy()
+    for f in range(0, 13000, 3):
+        kind = (f // 3) % 3
+        if kind == 0:
+            llrs[f, (f * 7) % code.n()] = -np.inf
+        elif kind == 1:
+            llrs[f] *= np.float32(1e37)
+    _compare(code, llrs, 15)
