@@ -81,7 +81,7 @@ def test_f32_corner_values(code):
     _compare(code, llrs, 20)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TM2048], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TM2048, LDPCCode.TM8192], ids=lambda c: c.name)
 @pytest.mark.parametrize("maxiters", [0, 1, 2, 3])
 def test_small_maxiters(code, maxiters):
     rng = np.random.default_rng(5)
