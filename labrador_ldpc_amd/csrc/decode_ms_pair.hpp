@@ -327,6 +327,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 });
                 const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
                 exclusive_min<O, D, true, CAP>(a, e);                                  // :391-395, :430-435
+#ifdef LDPC_PAIR_TAIL_PRIO
+                if constexpr (Rw == NROWS - 1 && S == IPT - 1) LDPC_SETPRIO(LDPC_PAIR_TAIL_PRIO);
+#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
