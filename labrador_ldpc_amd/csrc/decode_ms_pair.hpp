@@ -47,6 +47,13 @@
 #ifndef LDPC_PAIR_NOCAP
 #define LDPC_PAIR_NOCAP 1
 #endif
+// How many of the thread's local-edge updates (of 14 on TM8192) are done at the end of the variable phase
+// (LDS-bound: the VALU idles there) instead of at the start of the check phase (VALU-bound), where the
+// rest still covers the latency of the marginal reads.  Sweep on TM8192: f32 0/3/5/7/9/14 -> 7.04 / 7.07 /
+// 7.24 / 7.41 / 7.32 / 7.26 M codewords/s; i8 0/4/7 -> 9.29 / 9.61 / 8.31.  -1 = per type (7 for f32, 4 else).
+#ifndef LDPC_PAIR_LOCAL_IN_VAR
+#define LDPC_PAIR_LOCAL_IN_VAR -1
+#endif
 #ifndef LDPC_PAIR_QMAP
 #define LDPC_PAIR_QMAP {0, 1, 2, 3}
 #endif
@@ -86,6 +93,15 @@ struct PairGeometry {
     static_assert(M % 512 == 0 && NT <= 1024, "pair ownership needs M/8 >= 64 lanes per quarter and <= 1024 threads");
 };
 
+// rank of local edge (S, B) among a thread's local edges, index-major
+constexpr int pair_local_rank(const Prototype &p, int S, int B)
+{
+    int nloc = 0, r = 0;
+    for (int b = 0; b < p.n_blocks; ++b)
+        if (blk_local(p.blk[b])) { if (b < B) ++r; ++nloc; }
+    return S * nloc + r;
+}
+
 constexpr bool all_exchanged_are_pi(const Prototype &p)
 {
     for (int b = 0; b < p.n_blocks; ++b)
@@ -111,6 +127,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     // odd rotations read their two marginals as halves of two aligned 64-bit pairs (see check_phase): +12 % for
     // i8 (8.0 -> 9.0 M codewords/s), but the wider destinations cost f32 nine spilled VGPRs (6.7 -> 6.5)
     constexpr bool ODD_B64 = LDPC_PAIR_ODD_B64 >= 0 ? LDPC_PAIR_ODD_B64 != 0 : !std::is_same_v<T, float>;
+    constexpr int LOCAL_IN_VAR = LDPC_PAIR_LOCAL_IN_VAR >= 0 ? LDPC_PAIR_LOCAL_IN_VAR : (std::is_same_v<T, float> ? 7 : 4);
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
 
@@ -191,6 +208,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         }
     };
 
+    auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
+        constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+        const R nv = O::sub(x, u[S][B]);                                               // :421
+        v[S][B] = O::template self_correct<true>(nv, v[S][B]);                         // :422-425
+    };
+
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
     auto variable_phase = [&]() LDPC_INLINE {
         int tq = t;
@@ -232,12 +255,14 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             constexpr int cs = col_slot(P, C);
             if constexpr (cs >= 0) lds2(lds_xva_off(P, cs, BLK_BYTES) + tb8) = ldpc_f2{O::store(acc0), O::store(acc1)};
         });
-    };
-
-    auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
-        constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-        const R nv = O::sub(x, u[S][B]);                                               // :421
-        v[S][B] = O::template self_correct<true>(nv, v[S][B]);                         // :422-425
+        // the local-edge part of the check update for the first LDPC_PAIR_LOCAL_IN_VAR indices, while the
+        // marginal stores drain (this phase is LDS-bound, the check phase VALU-bound)
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
+            });
+        });
     };
 
     // ---- check phase (decoder.rs:414-450 and :391-405 of the next iteration) -------------------------
@@ -289,7 +314,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2) local edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col]);
+                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) >= LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
             });
         });
         if constexpr (LDPC_PAIR_LATE_ODD) request(IC<1>{});
