@@ -80,6 +80,9 @@
 #ifndef LDPC_NOCAP
 #define LDPC_NOCAP 1
 #endif
+#ifndef LDPC_LOCAL_IN_VAR
+#define LDPC_LOCAL_IN_VAR -1       // -1 = per kernel (local_in_var_default), >= 0 forces the count (experiments)
+#endif
 #ifndef LDPC_ADDTID
 #define LDPC_ADDTID 0
 #endif
@@ -434,6 +437,24 @@ constexpr int lds_bias(const Prototype &p, int b, int blk_bytes)
     return a0 < a1 ? a0 : a1;
 }
 
+// rank of local edge (S, B) among a thread's local edges, index-major
+constexpr int local_edge_rank(const Prototype &p, int S, int B)
+{
+    int nloc = 0, r = 0;
+    for (int b = 0; b < p.n_blocks; ++b)
+        if (blk_local(p.blk[b])) { if (b < B) ++r; ++nloc; }
+    return S * nloc + r;
+}
+// local-edge updates done in the variable phase (see LOCAL_IN_VAR in the kernel body)
+template <int CODE, class T, int IPT, int LEAN>
+constexpr int local_in_var_default()
+{
+    // pays where ONE workgroup has a CU to itself (nothing else fills the idle VALU of its variable phase):
+    // TM6144 f32 0/3/5/9/12 -> 10.83 / 11.05 / 11.12 / 11.13 / 11.14 M codewords/s; no effect on TM2048,
+    // TM1536, TM1280, where several workgroups share a CU
+    return (CODE == TM6144 && IPT == 1 && LEAN == 0) ? 9 : 0;
+}
+
 // ---- kernel geometry -----------------------------------------------------------------------
 template <int CODE, class T, int IPT>
 struct Geometry {
@@ -712,6 +733,33 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
+    auto edge_update = [&](auto S_, auto B_, R x, R uu) LDPC_INLINE {
+        constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+        const R nv = O::sub(x, uu);                                                    // :421
+        // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
+#ifdef LDPC_DIAG_NOSELFCORR
+        const R nw = nv;
+#else
+        const R nw = O::template self_correct<G == 1>(nv, v[S][B]);
+#endif
+        v[S][B] = nw;
+    };
+    // the part of the check update that needs no exchanged data: the LOCAL edges
+    // The first LOCAL_IN_VAR of them (index-major rank) are done at the END of the variable phase -- LDS-bound,
+    // the VALU idles there -- the rest at the start of the check phase, where they cover the latency of the
+    // marginal reads (TM8192 pair kernel: +5 %; per-code values measured with tools/kbench.hip).
+    constexpr int LOCAL_IN_VAR = LDPC_LOCAL_IN_VAR >= 0 ? LDPC_LOCAL_IN_VAR : local_in_var_default<CODE, T, IPT, LEAN>();
+    auto local_edges = [&](auto EARLY_) LDPC_INLINE {
+        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+            static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                if constexpr (exch_slot(P, B) < 0 && (local_edge_rank(P, S, B) < LOCAL_IN_VAR) == (decltype(EARLY_)::value != 0))
+                    edge_update(S_, B_, va[S][P.blk[B].col], u[S][B]);
+            });
+        });
+    };
+    auto check_local = [&]() LDPC_INLINE { local_edges(IC<0>{}); };
+
     // bit pattern (sign in bit 31) of the marginal of variable (S, C) of this thread
     auto marginal_bits = [&](auto S_, auto C_) LDPC_INLINE -> int {
         constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
@@ -782,27 +830,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 }
             });
         });
-    };
-
-    auto edge_update = [&](auto S_, auto B_, R x, R uu) LDPC_INLINE {
-        constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-        const R nv = O::sub(x, uu);                                                    // :421
-        // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
-#ifdef LDPC_DIAG_NOSELFCORR
-        const R nw = nv;
-#else
-        const R nw = O::template self_correct<G == 1>(nv, v[S][B]);
-#endif
-        v[S][B] = nw;
-    };
-    // the part of the check update that needs no exchanged data: the LOCAL edges
-    auto check_local = [&]() LDPC_INLINE {
-        static_for<0, IPT>([&](auto S_) LDPC_INLINE {
-            static_for<0, NB>([&](auto B_) LDPC_INLINE {
-                constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0) edge_update(S_, B_, va[S][P.blk[B].col], u[S][B]);
-            });
-        });
+        if constexpr (LEAN == 0) local_edges(IC<1>{});
     };
 
     auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
