@@ -452,7 +452,8 @@ constexpr int local_in_var_default()
     // pays where ONE workgroup has a CU to itself (nothing else fills the idle VALU of its variable phase):
     // TM6144 f32 0/3/5/9/12 -> 10.83 / 11.05 / 11.12 / 11.13 / 11.14 M codewords/s; no effect on TM2048,
     // TM1536, TM1280, where several workgroups share a CU
-    return (CODE == TM6144 && IPT == 1 && LEAN == 0) ? 9 : 0;
+    // (i8/i16 TM6144: 10.08 / 9.91 / 9.86 at 0 / 4 / 9 -- their variable phase carries the clamps already)
+    return (CODE == TM6144 && IPT == 1 && LEAN == 0 && std::is_same_v<T, float>) ? 9 : 0;
 }
 
 // ---- kernel geometry -----------------------------------------------------------------------
