@@ -2,7 +2,7 @@
 // PAIR ownership: thread t owns the ADJACENT indices 2t and 2t+1 (check 2t, 2t+1 of every block row
 // and variable 2t, 2t+1 of every block column) instead of t and t + M/2 as decode_ms_kernel.hpp does.
 //
-// Why: the LDS, not the VALU, bounds the variable phase of the big codes (DESIGN.md 4.4), and a
+// Why: the LDS, not the VALU, bounds the variable phase of the big codes (DESIGN.md 4.1b, 4.4), and a
 // ds_write_b32 costs twice a ds_read_b32.  With adjacent indices
 //   * every access at the thread's own position (u reads and marginal stores of the variable phase)
 //     is one 64-bit LDS operation for both indices;
@@ -22,56 +22,61 @@
 
 #include "decode_ms_kernel.hpp"
 
-// Experiment switch: re-read the LLRs from L2 every iteration instead of holding them in 8 VGPRs.
-#ifndef LDPC_PAIR_RELOAD_LLR
-#define LDPC_PAIR_RELOAD_LLR 0
-#endif
-#ifndef LDPC_PAIR_ODD_B64
-#define LDPC_PAIR_ODD_B64 -1      // -1 = per type (see ODD_B64), 0 / 1 = force
-#endif
-// Experiment switch: request the marginals of the odd rotations after the local-edge work instead of first.
-#ifndef LDPC_PAIR_LATE_ODD
-#define LDPC_PAIR_LATE_ODD 0
-#endif
-#ifndef LDPC_PRIO_ROWS_PAIR
-#define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}   // wave priority over the six (check row, index) steps, see LDPC_PRIO
-#endif
-// Which quarter the k-th group of waves (oldest first) works on.
-// Issue the next codeword's LLR loads before this one's epilogue: the fixed cost per codeword drops from
-// 2.55 to 2.12 us (1.305 -> 1.086 ms per 131 072 frames at 0 iterations), +0.7 % at 25.
-#ifndef LDPC_PAIR_EARLY_FETCH
-#define LDPC_PAIR_EARLY_FETCH 1
-#endif
-// f32: run the check phase without the FLT_MAX clamp of the exclusive minimum when no LLR of the codeword
-// exceeds 2^100 in magnitude (see begin_codeword).
-#ifndef LDPC_PAIR_NOCAP
-#define LDPC_PAIR_NOCAP 1
-#endif
+// ---- tuned settings (each measured with tools/kbench.hip -DKPAIR=1 on TM8192) --------------------------
 // How many of the thread's local-edge updates (of 14 on TM8192) are done at the end of the variable phase
 // (LDS-bound: the VALU idles there) instead of at the start of the check phase (VALU-bound), where the
-// rest still covers the latency of the marginal reads.  Sweep on TM8192: f32 0/3/5/7/9/14 -> 7.04 / 7.07 /
-// 7.24 / 7.41 / 7.32 / 7.26 M codewords/s; i8 0/4/7 -> 9.29 / 9.61 / 8.31.  -1 = per type (7 for f32, 4 else).
+// rest still covers the latency of the marginal reads.  f32 0/3/5/7/9/14 -> 7.04 / 7.07 / 7.24 / 7.41 /
+// 7.32 / 7.26 M codewords/s; i8 0/4/7 -> 9.29 / 9.61 / 8.31.  -1 = per type (7 for f32, 4 else).
 #ifndef LDPC_PAIR_LOCAL_IN_VAR
 #define LDPC_PAIR_LOCAL_IN_VAR -1
 #endif
+// f32: run the check phase without the FLT_MAX clamp of the exclusive minimum when no LLR of the codeword
+// exceeds 2^100 in magnitude (see begin_codeword): 6.84 -> 7.05.
+#ifndef LDPC_PAIR_NOCAP
+#define LDPC_PAIR_NOCAP 1
+#endif
+// Issue the next codeword's LLR loads before this one's epilogue: the fixed cost per codeword drops from
+// 2.55 to 2.12 us (1.305 -> 1.086 ms per 131 072 frames at 0 iterations), +0.7 % at 25 iterations.
+#ifndef LDPC_PAIR_EARLY_FETCH
+#define LDPC_PAIR_EARLY_FETCH 1
+#endif
+// Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = per type (on for
+// i8/i16: 8.0 -> 9.0; off for f32: 7.05 -> 6.90), 0 / 1 = force.
+#ifndef LDPC_PAIR_ODD_B64
+#define LDPC_PAIR_ODD_B64 -1
+#endif
+// Wave priority (see LDPC_PRIO in decode_ms_kernel.hpp) over the six (check row, index) steps of the check
+// phase; 3 before them.  A dozen alternatives, also per quarter, measured 6.4-6.75 against 6.75 for this one.
+#ifndef LDPC_PRIO_ROWS_PAIR
+#define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}
+#endif
+
+// ---- experiment switches, all measured slower or equal and left off ---------------------------------------
+#ifndef LDPC_PAIR_RELOAD_LLR
+#define LDPC_PAIR_RELOAD_LLR 0    // re-read the LLRs from L2 every iteration instead of holding 8 VGPRs: 6.63 -> 6.00
+#endif
+#ifndef LDPC_PAIR_LATE_ODD
+#define LDPC_PAIR_LATE_ODD 0      // request the marginals of the odd rotations after the local-edge work: -1 %
+#endif
 #ifndef LDPC_PAIR_QMAP
-#define LDPC_PAIR_QMAP {0, 1, 2, 3}
+#define LDPC_PAIR_QMAP {0, 1, 2, 3}           // which quarter the k-th group of four waves (oldest first) works on
 #endif
 #ifndef LDPC_PAIR_HEAD_Q
-#define LDPC_PAIR_HEAD_Q {3, 3, 3, 3}      // priority of the request / edge-update stages of the check phase, per quarter
+#define LDPC_PAIR_HEAD_Q {3, 3, 3, 3}         // per quarter: priority of the request / edge-update stages
 #endif
 #ifndef LDPC_PAIR_VAR_Q
-#define LDPC_PAIR_VAR_Q {LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR}   // first half of the variable phase
+#define LDPC_PAIR_VAR_Q {LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR}   // ... of the first half of the variable phase
 #endif
 #ifndef LDPC_PAIR_VAR2_Q
-#define LDPC_PAIR_VAR2_Q {0, 0, 0, 0}      // second half of the variable phase
+#define LDPC_PAIR_VAR2_Q {0, 0, 0, 0}         // ... of its second half
 #endif
-#ifndef LDPC_PRIO_ROWS_PAIR_Q0
+#ifndef LDPC_PRIO_ROWS_PAIR_Q0                // per quarter: the table above
 #define LDPC_PRIO_ROWS_PAIR_Q0 LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR_Q1 LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR_Q2 LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR_Q3 LDPC_PRIO_ROWS_PAIR
 #endif
+// (also: LDPC_PAIR_TAIL_PRIO = extra priority step inside the last row, LDPC_DIAG_STAMPS = per-phase s_memtime sums)
 
 namespace ldpc {
 
