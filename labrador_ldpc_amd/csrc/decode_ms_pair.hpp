@@ -52,6 +52,12 @@
 #endif
 
 // ---- experiment switches, all measured slower or equal and left off ---------------------------------------
+#ifndef LDPC_PAIR_LOCAL_INTERLEAVED
+#define LDPC_PAIR_LOCAL_INTERLEAVED 0   // the moved local-edge updates after each column instead of after all
+#endif
+#ifndef LDPC_PAIR_ROWWISE
+#define LDPC_PAIR_ROWWISE 0              // update the exchanged edges row by row, right before the row's minima
+#endif
 #ifndef LDPC_PAIR_RELOAD_LLR
 #define LDPC_PAIR_RELOAD_LLR 0    // re-read the LLRs from L2 every iteration instead of holding 8 VGPRs: 6.63 -> 6.00
 #endif
@@ -259,15 +265,25 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             va[1][C] = acc1;
             constexpr int cs = col_slot(P, C);
             if constexpr (cs >= 0) lds2(lds_xva_off(P, cs, BLK_BYTES) + tb8) = ldpc_f2{O::store(acc0), O::store(acc1)};
+#if LDPC_PAIR_LOCAL_INTERLEAVED
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {                               // this column's moved local edges right away
+                static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                    constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                    if constexpr (exch_slot(P, B) < 0 && P.blk[B].col == C && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][C]);
+                });
+            });
+#endif
         });
         // the local-edge part of the check update for the first LDPC_PAIR_LOCAL_IN_VAR indices, while the
         // marginal stores drain (this phase is LDS-bound, the check phase VALU-bound)
+#if !LDPC_PAIR_LOCAL_INTERLEAVED
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
             });
         });
+#endif
     };
 
     // ---- check phase (decoder.rs:414-450 and :391-405 of the next iteration) -------------------------
@@ -324,12 +340,14 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         });
         if constexpr (LDPC_PAIR_LATE_ODD) request(IC<1>{});
         __builtin_amdgcn_sched_barrier(0);
+#if !LDPC_PAIR_ROWWISE
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B]);
             });
         });
+#endif
         static_for<0, NROWS>([&](auto R_) LDPC_INLINE {                                // (4) per check row, both indices
             constexpr int Rw = decltype(R_)::value;
             constexpr int D = row_degree(P, Rw);
@@ -347,6 +365,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 }
                 R a[D], e[D];
                 int sr[D], xw[D];
+#if LDPC_PAIR_ROWWISE
+                static_for<0, D>([&](auto J_) LDPC_INLINE {                            // (3) this row's exchanged edges
+                    constexpr int B = row_block(P, Rw, decltype(J_)::value);
+                    if constexpr (exch_slot(P, B) >= 0) edge_update(S_, IC<B>{}, xs[S][B]);
+                });
+#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
