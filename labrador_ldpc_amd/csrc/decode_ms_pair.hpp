@@ -55,6 +55,9 @@
 #ifndef LDPC_PAIR_LOCAL_INTERLEAVED
 #define LDPC_PAIR_LOCAL_INTERLEAVED 0   // the moved local-edge updates after each column instead of after all
 #endif
+#ifndef LDPC_PAIR_SKIP_FIRST
+#define LDPC_PAIR_SKIP_FIRST 0           // iteration 0 without the (all-zero) u reads and slot zeroing: 1.94 vs 2.04 ms per 131 072 frames
+#endif                                   // at one iteration, but the second copy of the variable phase costs 6 % at 25 (7.42 -> 6.94)
 #ifndef LDPC_PAIR_ROWWISE
 #define LDPC_PAIR_ROWWISE 0              // update the exchanged edges row by row, right before the row's minima
 #endif
@@ -200,9 +203,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
             static_for<0, NTX>([&](auto C_) LDPC_INLINE { llr[S][decltype(C_)::value] = O::load(lraw[S][decltype(C_)::value]); });
         });
+#if !LDPC_PAIR_SKIP_FIRST
         static_for<0, NX>([&](auto X_) LDPC_INLINE {                                   // u = 0 in every exchange slot
             lds2(lds_xu_off(P, decltype(X_)::value, BLK_BYTES) + tb8) = ldpc_f2{0.0f, 0.0f};
         });
+#endif
         if (t < 2) flag_at(t) = 0;
         // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
         // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
@@ -226,7 +231,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
-    auto variable_phase = [&]() LDPC_INLINE {
+    auto variable_phase = [&](auto FIRST_) LDPC_INLINE {
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;   // iteration 0: every u is zero, va = llr exactly (llr + 0.0 = llr)
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
@@ -247,6 +253,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 acc0 = llr[0][C]; acc1 = llr[1][C];
 #endif
             }
+            if constexpr (!FIRST)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int B = decltype(B_)::value;
                 if constexpr (P.blk[B].col == C) {
@@ -429,7 +436,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
                 else if (it == maxiters) { done = true; }
                 if (done) break;
-                variable_phase();
+#if LDPC_PAIR_SKIP_FIRST
+                if (it == 0) variable_phase(IC<1>{});     // nothing to read yet: the exchange slots are not even zeroed
+                else variable_phase(IC<0>{});
+#else
+                variable_phase(IC<0>{});
+#endif
 #ifdef LDPC_DIAG_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
