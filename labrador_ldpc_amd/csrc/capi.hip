@@ -154,6 +154,30 @@ thread_local PipeStreams g_pipe;
 
 struct HostOut { void *host; size_t bytes_per_item; };
 
+// Small calls (the reference-shaped single-frame entry points above all) go through one pinned host
+// buffer per thread: one copy in, one copy out of a single device block holding all outputs, instead of
+// four pageable copies -- the call's latency is mostly copy and synchronisation overhead.
+struct PinnedStage {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~PinnedStage() { if (p) (void)hipHostFree(p); }
+    hipError_t get(size_t bytes, void **out)
+    {
+        if (cap < bytes) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
+            hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+            if (e != hipSuccess) { p = nullptr; return e; }
+            cap = want;
+        }
+        *out = p;
+        return hipSuccess;
+    }
+};
+thread_local PinnedStage g_pinned;
+constexpr size_t SMALL_CALL_BYTES = 1u << 20;
+
 // frames per chunk: about 128 MB of input, at least 8192 frames (the persistent kernels want
 // tens of codewords per workgroup), at most 262144
 // (LABRADOR_LDPC_HIP_CHUNK=<frames> overrides, for tests and tuning).
@@ -175,6 +199,28 @@ int host_pipeline(const void *in, size_t in_bytes_per_item, const HostOut (&outs
                   hipStream_t user_stream, Launch launch)
 {
     static_assert(NOUT >= 1 && NOUT <= 3, "two staging sets of 1 + NOUT buffers share the 8 pool slots");
+    {   // small call: pinned staging, one device block for all outputs
+        size_t out_off[NOUT + 1];
+        out_off[0] = 0;
+        for (int o = 0; o < NOUT; ++o) out_off[o + 1] = (out_off[o] + items * outs[o].bytes_per_item + 15) / 16 * 16;
+        const size_t in_total = items * in_bytes_per_item, in_pad = (in_total + 15) / 16 * 16;
+        if (in_pad + out_off[NOUT] <= SMALL_CALL_BYTES) {
+            void *hbuf = nullptr, *dbuf_in = nullptr, *dbuf_out = nullptr;
+            HIP_TRY(g_pinned.get(in_pad + out_off[NOUT], &hbuf));
+            HIP_TRY(g_pool.get(0, in_pad, &dbuf_in));
+            HIP_TRY(g_pool.get(1, out_off[NOUT], &dbuf_out));
+            char *h_in = static_cast<char *>(hbuf), *h_out = h_in + in_pad;
+            std::memcpy(h_in, in, in_total);
+            HIP_TRY(hipMemcpyAsync(dbuf_in, h_in, in_total, hipMemcpyHostToDevice, user_stream));
+            void *d_outs[NOUT];
+            for (int o = 0; o < NOUT; ++o) d_outs[o] = static_cast<char *>(dbuf_out) + out_off[o];
+            if (int st = launch(dbuf_in, d_outs, (size_t)0, items, user_stream)) return st;
+            HIP_TRY(hipMemcpyAsync(h_out, dbuf_out, out_off[NOUT], hipMemcpyDeviceToHost, user_stream));
+            HIP_TRY(hipStreamSynchronize(user_stream));
+            for (int o = 0; o < NOUT; ++o) std::memcpy(outs[o].host, h_out + out_off[o], items * outs[o].bytes_per_item);
+            return LABRADOR_LDPC_HIP_OK;
+        }
+    }
     const size_t chunk_max = chunk_items(in_bytes_per_item);
     const size_t chunk = items < chunk_max ? items : chunk_max;
     const size_t nchunks = (items + chunk - 1) / chunk;
