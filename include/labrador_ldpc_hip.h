@@ -43,6 +43,116 @@ enum labrador_ldpc_code {
     LABRADOR_LDPC_CODE_TM8192   = 8,
 };
 
+/* --------------------------------------------------------------------------------------
+ * Compile-time sizes for static allocation (capi/include/labrador_ldpc.h:30-115; used by the
+ * reference's C client capi/examples/example.c:23-37).  Every quantity Q in
+ *   N  K  BF_WORKING_LEN  MS_WORKING_LEN  MS_WORKING_U8_LEN  OUTPUT_LEN
+ * is available as LABRADOR_LDPC_<Q>_<code> and as LABRADOR_LDPC_<Q>(CODE), where CODE may itself
+ * be a macro naming a code (two-level expansion), and LABRADOR_LDPC_CODE(CODE) gives the enum
+ * constant.  Values follow src/codes/mod.rs:109-241 / src/decoder.rs:93-116:
+ *   BF_WORKING_LEN = n+p, MS_WORKING_LEN = 2E+3n+3p-2k, MS_WORKING_U8_LEN = (n+p-k)/8,
+ *   OUTPUT_LEN = (n+p)/8
+ * and are checked against the labrador_ldpc_*_len() functions by tests/test_c_boundary.py.
+ * Reference quirks: its header spells the TM6144 entries of the four *_LEN families "_TM6140"
+ * (labrador_ldpc.h:76,:88,:100,:112) and gives LABRADOR_LDPC_N_TM6144 the value 6140 (:52), which
+ * is wrong (n = 6144, src/codes/mod.rs:203-213).  Here the _TM6140 spellings are kept as aliases
+ * so existing sources compile, _TM6144 spellings are added so the (CODE) forms work for TM6144,
+ * and N_TM6144 carries the correct value 6144.
+ * -------------------------------------------------------------------------------------- */
+#define LABRADOR_LDPC_PASTE_(FAMILY, CODE)   FAMILY##CODE
+#define LABRADOR_LDPC_CODE(CODE)              LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_CODE_, CODE)
+#define LABRADOR_LDPC_N(CODE)                 LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_N_, CODE)
+#define LABRADOR_LDPC_K(CODE)                 LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_K_, CODE)
+#define LABRADOR_LDPC_BF_WORKING_LEN(CODE)    LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_BF_WORKING_LEN_, CODE)
+#define LABRADOR_LDPC_MS_WORKING_LEN(CODE)    LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_MS_WORKING_LEN_, CODE)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN(CODE) LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_MS_WORKING_U8_LEN_, CODE)
+#define LABRADOR_LDPC_OUTPUT_LEN(CODE)        LABRADOR_LDPC_PASTE_(LABRADOR_LDPC_OUTPUT_LEN_, CODE)
+/* the reference's one-argument helper spellings (labrador_ldpc.h:42, :53, ...), kept for sources that use them */
+#define LABRADOR_LDPC_CODE_(CODE)              LABRADOR_LDPC_CODE_##CODE
+#define LABRADOR_LDPC_N_(CODE)                 LABRADOR_LDPC_N_##CODE
+#define LABRADOR_LDPC_K_(CODE)                 LABRADOR_LDPC_K_##CODE
+#define LABRADOR_LDPC_BF_WORKING_LEN_(CODE)    LABRADOR_LDPC_BF_WORKING_LEN_##CODE
+#define LABRADOR_LDPC_MS_WORKING_LEN_(CODE)    LABRADOR_LDPC_MS_WORKING_LEN_##CODE
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_(CODE) LABRADOR_LDPC_MS_WORKING_U8_LEN_##CODE
+#define LABRADOR_LDPC_OUTPUT_LEN_(CODE)        LABRADOR_LDPC_OUTPUT_LEN_##CODE
+
+/* TC128: n=128 k=64 punctured=0 edges=512 */
+#define LABRADOR_LDPC_N_TC128                   (128)
+#define LABRADOR_LDPC_K_TC128                   (64)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TC128      (128)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TC128      (1280)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TC128   (8)
+#define LABRADOR_LDPC_OUTPUT_LEN_TC128          (16)
+
+/* TC256: n=256 k=128 punctured=0 edges=1024 */
+#define LABRADOR_LDPC_N_TC256                   (256)
+#define LABRADOR_LDPC_K_TC256                   (128)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TC256      (256)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TC256      (2560)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TC256   (16)
+#define LABRADOR_LDPC_OUTPUT_LEN_TC256          (32)
+
+/* TC512: n=512 k=256 punctured=0 edges=2048 */
+#define LABRADOR_LDPC_N_TC512                   (512)
+#define LABRADOR_LDPC_K_TC512                   (256)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TC512      (512)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TC512      (5120)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TC512   (32)
+#define LABRADOR_LDPC_OUTPUT_LEN_TC512          (64)
+
+/* TM1280: n=1280 k=1024 punctured=128 edges=4992 */
+#define LABRADOR_LDPC_N_TM1280                  (1280)
+#define LABRADOR_LDPC_K_TM1280                  (1024)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM1280     (1408)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM1280     (12160)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM1280  (48)
+#define LABRADOR_LDPC_OUTPUT_LEN_TM1280         (176)
+
+/* TM1536: n=1536 k=1024 punctured=256 edges=5888 */
+#define LABRADOR_LDPC_N_TM1536                  (1536)
+#define LABRADOR_LDPC_K_TM1536                  (1024)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM1536     (1792)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM1536     (15104)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM1536  (96)
+#define LABRADOR_LDPC_OUTPUT_LEN_TM1536         (224)
+
+/* TM2048: n=2048 k=1024 punctured=512 edges=7680 */
+#define LABRADOR_LDPC_N_TM2048                  (2048)
+#define LABRADOR_LDPC_K_TM2048                  (1024)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM2048     (2560)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM2048     (20992)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM2048  (192)
+#define LABRADOR_LDPC_OUTPUT_LEN_TM2048         (320)
+
+/* TM5120: n=5120 k=4096 punctured=512 edges=19968 */
+#define LABRADOR_LDPC_N_TM5120                  (5120)
+#define LABRADOR_LDPC_K_TM5120                  (4096)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM5120     (5632)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM5120     (48640)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM5120  (192)
+#define LABRADOR_LDPC_OUTPUT_LEN_TM5120         (704)
+
+/* TM6144: n=6144 k=4096 punctured=1024 edges=23552 */
+#define LABRADOR_LDPC_N_TM6144                  (6144)
+#define LABRADOR_LDPC_K_TM6144                  (4096)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM6144     (7168)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM6144     (60416)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM6144  (384)
+#define LABRADOR_LDPC_OUTPUT_LEN_TM6144         (896)
+/* reference spellings of the four entries above (labrador_ldpc.h:76, :88, :100, :112) */
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM6140     LABRADOR_LDPC_BF_WORKING_LEN_TM6144
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM6140     LABRADOR_LDPC_MS_WORKING_LEN_TM6144
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM6140  LABRADOR_LDPC_MS_WORKING_U8_LEN_TM6144
+#define LABRADOR_LDPC_OUTPUT_LEN_TM6140         LABRADOR_LDPC_OUTPUT_LEN_TM6144
+
+/* TM8192: n=8192 k=4096 punctured=2048 edges=30720 */
+#define LABRADOR_LDPC_N_TM8192                  (8192)
+#define LABRADOR_LDPC_K_TM8192                  (4096)
+#define LABRADOR_LDPC_BF_WORKING_LEN_TM8192     (10240)
+#define LABRADOR_LDPC_MS_WORKING_LEN_TM8192     (83968)
+#define LABRADOR_LDPC_MS_WORKING_U8_LEN_TM8192  (768)
+#define LABRADOR_LDPC_OUTPUT_LEN_TM8192         (1280)
+
 /* ======================================================================================
  * Part 1 -- the reference's 21 symbols, same names, signatures and meaning.
  * ====================================================================================== */
