@@ -219,14 +219,30 @@ void labrador_ldpc_llrs_to_hard_f64(enum labrador_ldpc_code code, const double  
 #define LABRADOR_LDPC_HIP_MEM_HOST    0      /* buffers are host memory; the call stages them */
 #define LABRADOR_LDPC_HIP_MEM_DEVICE  1      /* buffers are device memory resident on `device` */
 
+#define LABRADOR_LDPC_HIP_DEVICE_CURRENT (-1)  /* the calling thread's current HIP device */
+#define LABRADOR_LDPC_HIP_DEVICE_ALL     (-2)  /* MEM_HOST only: shard the batch over every gfx950 device */
+
+/* Zero-initialise, then set what you need: `struct labrador_ldpc_hip_opts o = {0};` means device 0,
+ * host memory, default stream, tuned kernel. */
 struct labrador_ldpc_hip_opts {
-    int   device;     /* HIP device ordinal; -1 = the calling thread's current device */
+    int   device;     /* HIP device ordinal, LABRADOR_LDPC_HIP_DEVICE_CURRENT or _ALL */
     int   memory;     /* LABRADOR_LDPC_HIP_MEM_HOST or _DEVICE */
     void *stream;     /* hipStream_t to launch on; NULL = the default stream.  With MEM_DEVICE
                          the call only enqueues work and returns (asynchronous); with MEM_HOST
                          it returns after the results are in the host buffers. */
     int   variant;    /* kernel variant; 0 = the tuned default (others: see DESIGN.md) */
+    int   n_devices;  /* > 0: shard a MEM_HOST batch over devices[0 .. n_devices) (`device` is ignored) */
+    const int *devices; /* HIP ordinals; an ordinal may repeat (that many host pipelines on it) */
 };
+
+/* Multi-GPU (the reference's analogue is perftest/src/main.rs:39-45, one worker per
+ * core over independent frames): with MEM_HOST buffers and a device set -- `device` ==
+ * LABRADOR_LDPC_HIP_DEVICE_ALL or a `devices` list -- the batched calls split the batch into
+ * contiguous slices (labrador_ldpc_hip_shard_range), one per listed device, and run every slice
+ * through that device's own copy/kernel/copy pipeline on a worker thread of the library.  No data
+ * moves between devices and there is no collective; results land in the caller's buffers exactly
+ * as in the single-device call.  `stream` must be NULL.  The first failing slice's status is
+ * returned (its text, prefixed with the device, via labrador_ldpc_hip_last_error()). */
 
 /* Decode `batch` independent frames.
  *   llrs    [batch][n]            row-major, n = labrador_ldpc_code_n(code)
@@ -284,6 +300,10 @@ int labrador_ldpc_hip_awgn_i8 (enum labrador_ldpc_code code, const uint8_t *code
  * test_iter_parity (src/codes/mod.rs:508-533).  Lets a test pin the tables the kernels are
  * generated from against the reference's nine known answers without a GPU. */
 uint32_t labrador_ldpc_hip_edge_crc(enum labrador_ldpc_code code);
+
+/* The contiguous slice [*first, *first + *count) of `batch` frames that part `index` of `parts`
+ * takes in a sharded call (slices differ by at most one frame).  Returns a status code. */
+int labrador_ldpc_hip_shard_range(size_t batch, size_t parts, size_t index, size_t *first, size_t *count);
 
 /* Number of HIP devices usable by this library (gfx950 only); 0 if none. Never fails. */
 int labrador_ldpc_hip_device_count(void);

@@ -31,10 +31,12 @@ class HipOpts(ctypes.Structure):
     """struct labrador_ldpc_hip_opts (include/labrador_ldpc_hip.h)."""
 
     _fields_ = [("device", ctypes.c_int), ("memory", ctypes.c_int),
-                ("stream", ctypes.c_void_p), ("variant", ctypes.c_int)]
+                ("stream", ctypes.c_void_p), ("variant", ctypes.c_int),
+                ("n_devices", ctypes.c_int), ("devices", ctypes.POINTER(ctypes.c_int))]
 
 
 MEM_HOST, MEM_DEVICE = 0, 1
+DEVICE_CURRENT, DEVICE_ALL = -1, -2
 
 _c = ctypes
 _sz, _vp, _int = _c.c_size_t, _c.c_void_p, _c.c_int
@@ -73,6 +75,7 @@ SYMBOLS = {
     "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
                                          _c.c_uint64, _optp]),
     "labrador_ldpc_hip_edge_crc": (_c.c_uint32, [_int]),
+    "labrador_ldpc_hip_shard_range": (_int, [_sz, _sz, _sz, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "labrador_ldpc_hip_device_count": (_int, []),
     "labrador_ldpc_hip_last_error": (_c.c_char_p, []),
     "labrador_ldpc_hip_version": (_c.c_char_p, []),
@@ -157,6 +160,42 @@ def _suffix(a) -> str:
         import torch
         return {torch.float32: "f32", torch.int8: "i8", torch.int16: "i16", torch.float64: "f64"}[a.dtype]
     return _NP_SUFFIX[a.dtype]
+
+
+def _host_opts(stream, variant: int, devices):
+    """opts for host (numpy) buffers.  `devices`: None = the current device, "all" = every gfx950
+    device, or a sequence of HIP ordinals (may repeat) to shard the batch over."""
+    if devices is None:
+        return HipOpts(DEVICE_CURRENT, MEM_HOST, stream, variant, 0, None), None
+    if stream is not None:
+        raise ValueError("a device set runs on the library's own streams: stream must be None")
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError('devices must be None, "all" or a sequence of device ordinals')
+        return HipOpts(DEVICE_ALL, MEM_HOST, None, variant, 0, None), None
+    devs = [int(d) for d in devices]
+    if not devs:
+        raise ValueError("empty device list")
+    arr = (ctypes.c_int * len(devs))(*devs)
+    return HipOpts(DEVICE_CURRENT, MEM_HOST, None, variant, len(devs), arr), arr   # keep arr alive during the call
+
+
+def _check_result_buffer(buf, like, shape, kinds, name: str):
+    """A caller-supplied result buffer is handed to the C ABI as a raw pointer: refuse anything the
+    kernel or the copy-out would overrun or misinterpret."""
+    if _is_torch(like):
+        import torch
+        ok_dtypes = {"u8": (torch.uint8,), "i32": (torch.int32, getattr(torch, "uint32", torch.int32))}[kinds]
+        if not _is_torch(buf) or buf.device != like.device:
+            raise ValueError(f"{name} must be a torch tensor on {like.device}")
+        if buf.dtype not in ok_dtypes or tuple(buf.shape) != shape or not buf.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous {kinds} tensor of shape {shape}")
+    else:
+        ok_dtypes = {"u8": (np.uint8,), "i32": (np.uint32, np.int32)}[kinds]
+        if not isinstance(buf, np.ndarray) or buf.dtype not in [np.dtype(d) for d in ok_dtypes]:
+            raise ValueError(f"{name} must be a numpy array of dtype {kinds}")
+        if buf.shape != shape or not buf.flags.c_contiguous or not buf.flags.writeable:
+            raise ValueError(f"{name} must be a writable C-contiguous array of shape {shape}")
 
 
 # (submatrix_size, circulant_size) per code: src/codes/mod.rs:109-241
@@ -263,25 +302,34 @@ class LDPCCode(enum.IntEnum):
         return bool(ok), int(iters.value)
 
     def decode_ms_batch(self, llrs, maxiters: int = 50, output=None, iters=None, success=None,
-                        variant: int = 0, stream: Optional[int] = None):
+                        variant: int = 0, stream: Optional[int] = None, devices=None):
         """Decode `llrs[batch, n]`.
 
         numpy arrays are host buffers (the call stages them and returns when results are
-        back); torch CUDA tensors are device-resident buffers: the call only enqueues the
+        back; `devices="all"` or a list of HIP ordinals shards the batch over several GPUs);
+        torch CUDA tensors are device-resident buffers: the call only enqueues the
         kernel on the tensor's device, on `stream` (default: torch's current stream).
         Returns (output[batch, output_len] u8, iters[batch] u32/i32, success[batch] u8)."""
+        if not (_is_torch(llrs) or isinstance(llrs, np.ndarray)):
+            raise ValueError("llrs must be a numpy array (host) or a torch CUDA tensor (device)")
         if llrs.ndim != 2 or llrs.shape[1] != self.n():
             raise ValueError("llrs must be [batch, n]")
         batch = llrs.shape[0]
-        fn = getattr(lib, "labrador_ldpc_decode_ms_batch_" + _suffix(llrs), None)
+        try:
+            fn = getattr(lib, "labrador_ldpc_decode_ms_batch_" + _suffix(llrs), None)
+        except KeyError:
+            fn = None
         if fn is None:
             raise LdpcHipError(f"no batched kernel for dtype {llrs.dtype}")
+        keep = None
         if _is_torch(llrs):
             import torch
             if not llrs.is_cuda:
                 raise ValueError("torch tensors must live on the GPU (use numpy for host buffers)")
             if not llrs.is_contiguous():
                 raise ValueError("llrs must be contiguous")
+            if devices is not None:
+                raise ValueError("device-resident buffers live on one device; `devices` is for host buffers")
             dev = llrs.device
             if output is None:
                 output = torch.empty((batch, self.output_len()), dtype=torch.uint8, device=dev)
@@ -291,7 +339,7 @@ class LDPCCode(enum.IntEnum):
                 success = torch.empty((batch,), dtype=torch.uint8, device=dev)
             if stream is None:
                 stream = torch.cuda.current_stream(dev).cuda_stream
-            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, variant)
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, variant, 0, None)
         else:
             llrs = np.ascontiguousarray(llrs)
             if output is None:
@@ -300,9 +348,13 @@ class LDPCCode(enum.IntEnum):
                 iters = np.empty((batch,), dtype=np.uint32)
             if success is None:
                 success = np.empty((batch,), dtype=np.uint8)
-            opts = HipOpts(-1, MEM_HOST, stream, variant)
+            opts, keep = _host_opts(stream, variant, devices)
+        _check_result_buffer(output, llrs, (batch, self.output_len()), "u8", "output")
+        _check_result_buffer(iters, llrs, (batch,), "i32", "iters")
+        _check_result_buffer(success, llrs, (batch,), "u8", "success")
         _check(fn(int(self), _ptr(llrs), _ptr(output), _ptr(iters), _ptr(success), batch, maxiters,
                   ctypes.byref(opts)))
+        del keep
         return output, iters, success
 
     # ---- bit-flipping decoder: src/decoder.rs:243-301 ----
@@ -320,7 +372,7 @@ class LDPCCode(enum.IntEnum):
             raise LdpcHipError(err)
         return bool(ok), int(iters.value)
 
-    def decode_bf_batch(self, input, maxiters: int = 50, stream: Optional[int] = None):
+    def decode_bf_batch(self, input, maxiters: int = 50, stream: Optional[int] = None, devices=None):
         """input[batch, n/8] -> (output[batch, output_len], iters[batch], success[batch]).
         numpy = host buffers, torch CUDA uint8 tensors = device buffers (asynchronous)."""
         if input.ndim != 2 or input.shape[1] != self.n() // 8:
@@ -336,18 +388,18 @@ class LDPCCode(enum.IntEnum):
             success = torch.empty((batch,), dtype=torch.uint8, device=dev)
             if stream is None:
                 stream = torch.cuda.current_stream(dev).cuda_stream
-            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0)
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0, 0, None)
         else:
             input = np.ascontiguousarray(input, dtype=np.uint8)
             output = np.empty((batch, self.output_len()), dtype=np.uint8)
             iters = np.empty((batch,), dtype=np.uint32)
             success = np.empty((batch,), dtype=np.uint8)
-            opts = HipOpts(-1, MEM_HOST, stream, 0)
+            opts, _keep = _host_opts(stream, 0, devices)
         _check(lib.labrador_ldpc_decode_bf_batch(int(self), _ptr(input), _ptr(output), _ptr(iters), _ptr(success),
                                                  batch, maxiters, ctypes.byref(opts)))
         return output, iters, success
 
-    def encode_batch(self, data, codewords=None, stream: Optional[int] = None):
+    def encode_batch(self, data, codewords=None, stream: Optional[int] = None, devices=None):
         """Batched `copy_encode`: data[batch, k/8] -> codewords[batch, n/8] on the GPU.
         numpy = host buffers (synchronous), torch CUDA uint8 tensors = device buffers (asynchronous)."""
         if data.ndim != 2 or data.shape[1] != self.k() // 8:
@@ -362,12 +414,13 @@ class LDPCCode(enum.IntEnum):
                 codewords = torch.empty((batch, self.n() // 8), dtype=torch.uint8, device=dev)
             if stream is None:
                 stream = torch.cuda.current_stream(dev).cuda_stream
-            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0)
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0, 0, None)
         else:
             data = np.ascontiguousarray(data, dtype=np.uint8)
             if codewords is None:
                 codewords = np.empty((batch, self.n() // 8), dtype=np.uint8)
-            opts = HipOpts(-1, MEM_HOST, stream, 0)
+            opts, _keep = _host_opts(stream, 0, devices)
+        _check_result_buffer(codewords, data, (batch, self.n() // 8), "u8", "codewords")
         _check(lib.labrador_ldpc_encode_batch(int(self), _ptr(data), _ptr(codewords), batch, ctypes.byref(opts)))
         return codewords
 
@@ -383,9 +436,12 @@ class LDPCCode(enum.IntEnum):
         tdt = {"f32": torch.float32, "i8": torch.int8}[dtype]
         if out is None:
             out = torch.empty((batch, self.n()), dtype=tdt, device=dev)
+        elif not (_is_torch(out) and out.device == dev and out.dtype == tdt and tuple(out.shape) == (batch, self.n())
+                  and out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous {tdt} tensor of shape ({batch}, {self.n()}) on {dev}")
         if stream is None:
             stream = torch.cuda.current_stream(dev).cuda_stream
-        opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0)
+        opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0, 0, None)
         if dtype == "f32":
             _check(lib.labrador_ldpc_hip_awgn_f32(int(self), codewords.data_ptr(), codewords.shape[0],
                                                   out.data_ptr(), batch, sigma, seed, ctypes.byref(opts)))

@@ -10,10 +10,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/labrador_ldpc_hip.h"
 #include "channel.hpp"
@@ -331,6 +335,154 @@ int host_pipeline(const void *in, size_t in_bytes_per_item, const HostOut (&outs
     return LABRADOR_LDPC_HIP_OK;
 }
 
+// ---- device-resident batches of any size ------------------------------------------------------------
+// The kernels take a 32-bit frame count.  A device-resident batch is enqueued as launches of at most
+// 2^30 frames (a multiple of every kernel's codewords-per-workgroup and of the 8-byte output alignment),
+// so no size_t batch is ever truncated.
+constexpr size_t MAX_LAUNCH_FRAMES = (size_t)1 << 30;
+
+template <class Launch>                                        // launch(first_frame, frames) -> hipError_t
+hipError_t for_launch_slices(size_t batch, Launch launch)
+{
+    for (size_t f0 = 0; f0 < batch; f0 += MAX_LAUNCH_FRAMES) {
+        const size_t nb = batch - f0 < MAX_LAUNCH_FRAMES ? batch - f0 : MAX_LAUNCH_FRAMES;
+        if (hipError_t e = launch(f0, nb); e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ---- host batches over several GPUs -------------------------------------------------------------------
+// Frames are independent (src/lib.rs:15-17), so a host batch splits into contiguous slices, one per
+// listed device, each run through that device's own host pipeline by a worker thread of this library
+// -- the shape of the reference's harness, one worker per core over independent frames
+// (perftest/src/main.rs:39-45), with GPUs for cores.  No data crosses between devices; the only
+// aggregation is the status.  Workers are persistent (their per-thread staging buffers, streams and
+// pinned memory survive between calls) and never destroyed: at process exit they are parked on their
+// condition variable.
+void shard_range(size_t total, size_t parts, size_t index, size_t *first, size_t *count)
+{
+    const size_t base = total / parts, extra = total % parts;
+    *first = index * base + (index < extra ? index : extra);
+    *count = base + (index < extra ? 1 : 0);
+}
+
+struct Worker {
+    struct Job {
+        std::function<int()> fn;
+        int status = LABRADOR_LDPC_HIP_OK;
+        std::string err;
+        bool done = false;
+    };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job *> queue;
+    Worker() { std::thread([this] { run(); }).detach(); }
+    void run()
+    {
+        for (;;) {
+            Job *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return !queue.empty(); });
+                j = queue.front();
+                queue.pop_front();
+            }
+            g_err.clear();
+            const int st = j->fn();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                j->status = st;
+                j->err = g_err;
+                j->done = true;
+            }
+            cv.notify_all();
+        }
+    }
+    void post(Job *j)
+    {
+        { std::lock_guard<std::mutex> lk(m); queue.push_back(j); }
+        cv.notify_all();
+    }
+    void wait(Job *j)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return j->done; });
+    }
+};
+
+Worker &worker(size_t slot)
+{
+    static std::mutex *m = new std::mutex;                       // leaked on purpose, see above
+    static std::vector<Worker *> *pool = new std::vector<Worker *>;
+    std::lock_guard<std::mutex> lk(*m);
+    while (pool->size() <= slot) pool->push_back(new Worker);
+    return *(*pool)[slot];
+}
+
+// The devices a call should shard over: empty = single-device call.  Returns a status.
+int device_set(const labrador_ldpc_hip_opts *opts, std::vector<int> &devs)
+{
+    devs.clear();
+    if (!opts) return LABRADOR_LDPC_HIP_OK;
+    const bool list = opts->n_devices > 0;
+    if (!list && opts->device != LABRADOR_LDPC_HIP_DEVICE_ALL) {
+        if (opts->n_devices < 0) return fail(LABRADOR_LDPC_HIP_EINVAL, "opts->n_devices is negative");
+        if (opts->device < LABRADOR_LDPC_HIP_DEVICE_ALL) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->device %d", opts->device);
+        return LABRADOR_LDPC_HIP_OK;
+    }
+    if (opts->memory != LABRADOR_LDPC_HIP_MEM_HOST)
+        return fail(LABRADOR_LDPC_HIP_EINVAL, "a device set needs MEM_HOST buffers (device memory lives on one device)");
+    if (opts->stream) return fail(LABRADOR_LDPC_HIP_EINVAL, "a device set runs on the library's own streams; opts->stream must be NULL");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(LABRADOR_LDPC_HIP_ENODEV, "no HIP device available (decode_ms has no CPU path)");
+    }
+    if (list) {
+        if (!opts->devices) return fail(LABRADOR_LDPC_HIP_EINVAL, "opts->n_devices > 0 but opts->devices is NULL");
+        if (opts->n_devices > 1024) return fail(LABRADOR_LDPC_HIP_EINVAL, "opts->n_devices too large");
+        for (int i = 0; i < opts->n_devices; ++i) {
+            const int d = opts->devices[i];
+            if (d < 0 || d >= count) return fail(LABRADOR_LDPC_HIP_EINVAL, "devices[%d] = %d out of range (%d devices)", i, d, count);
+            if (!device_is_gfx950(d)) return fail(LABRADOR_LDPC_HIP_ENODEV, "device %d is not gfx950", d);
+            devs.push_back(d);
+        }
+    } else {
+        for (int d = 0; d < count; ++d)
+            if (device_is_gfx950(d)) devs.push_back(d);
+        if (devs.empty()) return fail(LABRADOR_LDPC_HIP_ENODEV, "no gfx950 device; this library carries gfx950 code only");
+    }
+    return LABRADOR_LDPC_HIP_OK;
+}
+
+// run(first_item, n_items, opts_for_one_device) -> status, once per device on that device's worker
+template <class Run>
+int run_sharded(const std::vector<int> &devs, size_t items, int variant, Run run)
+{
+    const size_t parts = devs.size();
+    std::vector<Worker::Job> jobs(parts);
+    std::vector<labrador_ldpc_hip_opts> sub(parts);
+    for (size_t i = 0; i < parts; ++i) {
+        size_t first, count;
+        shard_range(items, parts, i, &first, &count);
+        sub[i] = labrador_ldpc_hip_opts{devs[i], LABRADOR_LDPC_HIP_MEM_HOST, nullptr, variant, 0, nullptr};
+        const labrador_ldpc_hip_opts *o = &sub[i];
+        jobs[i].fn = [=]() -> int { return count ? run(first, count, o) : LABRADOR_LDPC_HIP_OK; };
+        worker(i).post(&jobs[i]);
+    }
+    int status = LABRADOR_LDPC_HIP_OK;
+    for (size_t i = 0; i < parts; ++i) {
+        worker(i).wait(&jobs[i]);
+        if (jobs[i].status != LABRADOR_LDPC_HIP_OK && status == LABRADOR_LDPC_HIP_OK) {
+            status = jobs[i].status;
+            char pre[48];
+            std::snprintf(pre, sizeof pre, "device %d: ", devs[i]);
+            g_err = pre + jobs[i].err;
+        }
+    }
+    return status;
+}
+
 template <class T>
 int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
                  size_t batch, size_t max_iters, const labrador_ldpc_hip_opts *opts)
@@ -345,12 +497,21 @@ int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint
     const int variant = opts ? opts->variant : 0;
     hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
 
+    std::vector<int> devs;
+    if (int s = device_set(opts, devs)) return s;
+    if (!devs.empty())
+        return run_sharded(devs, batch, variant, [=](size_t f0, size_t nb, const labrador_ldpc_hip_opts *o) -> int {
+            return decode_batch<T>(code, llrs + f0 * n, output + f0 * out_len, iters + f0, success + f0, nb, max_iters, o);
+        });
+
     DeviceScope scope;
     if (int s = scope.enter(opts)) return s;
 
     if (opts && opts->memory == LABRADOR_LDPC_HIP_MEM_DEVICE) {
         if ((uintptr_t)output % 8) return fail(LABRADOR_LDPC_HIP_EINVAL, "device output buffer must be 8-byte aligned");
-        hipError_t e = ldpc::launch_decode_ms<T>(code, variant, llrs, output, iters, success, batch, maxit, stream);
+        hipError_t e = for_launch_slices(batch, [&](size_t f0, size_t nb) {
+            return ldpc::launch_decode_ms<T>(code, variant, llrs + f0 * n, output + f0 * out_len, iters + f0, success + f0, nb, maxit, stream);
+        });
         if (e == hipErrorInvalidConfiguration)
             return fail(LABRADOR_LDPC_HIP_EUNSUPPORTED, "kernel variant %d not built for code %d", variant, code);
         if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "kernel launch: %s", hipGetErrorString(e));
@@ -378,10 +539,7 @@ bool decode_one(int code, const T *llrs, uint8_t *output, size_t max_iters, size
     uint32_t it = 0;
     uint8_t ok = 0;
     const int s = decode_batch<T>(code, llrs, output, &it, &ok, 1, max_iters, nullptr);
-    if (s != LABRADOR_LDPC_HIP_OK) {
-        std::fprintf(stderr, "labrador_ldpc_hip: decode_ms failed: %s\n", g_err.c_str());
-        return false;
-    }
+    if (s != LABRADOR_LDPC_HIP_OK) return false;        // silent like the reference boundary; reason: labrador_ldpc_hip_last_error()
     // iters is clamped to 32 bits inside the kernel; report the caller's own bound on failure
     if (iters_run) *iters_run = ok ? (size_t)it : max_iters;
     return ok != 0;
@@ -462,10 +620,18 @@ int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code c, const uint8_t *inpu
     const uint32_t maxit = max_iters > 0x7FFFFFFEull ? 0x7FFFFFFEu : (uint32_t)max_iters;
     const size_t in_len = ldpc::CODES[c].n / 8, out_len = ldpc::CODES[c].output_len();
     hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+    std::vector<int> devs;
+    if (int s = device_set(opts, devs)) return s;
+    if (!devs.empty())
+        return run_sharded(devs, batch, 0, [=](size_t f0, size_t nb, const labrador_ldpc_hip_opts *o) -> int {
+            return labrador_ldpc_decode_bf_batch(c, input + f0 * in_len, output + f0 * out_len, iters + f0, success + f0, nb, max_iters, o);
+        });
     DeviceScope scope;
     if (int s = scope.enter(opts)) return s;
     if (opts && opts->memory == LABRADOR_LDPC_HIP_MEM_DEVICE) {
-        hipError_t e = ldpc::launch_decode_bf(c, input, output, iters, success, batch, maxit, stream);
+        hipError_t e = for_launch_slices(batch, [&](size_t f0, size_t nb) {
+            return ldpc::launch_decode_bf(c, input + f0 * in_len, output + f0 * out_len, iters + f0, success + f0, nb, maxit, stream);
+        });
         if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "decode_bf launch: %s", hipGetErrorString(e));
         return LABRADOR_LDPC_HIP_OK;
     }
@@ -486,10 +652,7 @@ bool labrador_ldpc_decode_bf(enum labrador_ldpc_code c, const uint8_t *input, ui
     uint32_t it = 0;
     uint8_t ok = 0;
     const int s = labrador_ldpc_decode_bf_batch(c, input, output, &it, &ok, 1, max_iters, nullptr);
-    if (s != LABRADOR_LDPC_HIP_OK) {
-        std::fprintf(stderr, "labrador_ldpc_hip: decode_bf failed: %s\n", g_err.c_str());
-        return false;
-    }
+    if (s != LABRADOR_LDPC_HIP_OK) return false;
     if (iters_run) *iters_run = ok ? (size_t)it : max_iters;
     return ok != 0;
 }
@@ -556,12 +719,20 @@ int labrador_ldpc_encode_batch(enum labrador_ldpc_code c, const uint8_t *data, u
     if (!data || !codewords) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
     const size_t kb = ldpc::CODES[c].k / 8, nb = ldpc::CODES[c].n / 8;
     hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+    std::vector<int> devs;
+    if (int s = device_set(opts, devs)) return s;
+    if (!devs.empty())
+        return run_sharded(devs, batch, 0, [=](size_t f0, size_t items, const labrador_ldpc_hip_opts *o) -> int {
+            return labrador_ldpc_encode_batch(c, data + f0 * kb, codewords + f0 * nb, items, o);
+        });
     DeviceScope scope;
     if (int s = scope.enter(opts)) return s;
     if (opts && opts->memory == LABRADOR_LDPC_HIP_MEM_DEVICE) {
         if ((uintptr_t)data % 4 || (uintptr_t)codewords % 4)
             return fail(LABRADOR_LDPC_HIP_EINVAL, "device buffers must be 4-byte aligned");
-        hipError_t e = ldpc::launch_encode(c, data, codewords, batch, stream);
+        hipError_t e = for_launch_slices(batch, [&](size_t f0, size_t items) {
+            return ldpc::launch_encode(c, data + f0 * kb, codewords + f0 * nb, items, stream);
+        });
         if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "encode launch: %s", hipGetErrorString(e));
         return LABRADOR_LDPC_HIP_OK;
     }
@@ -609,6 +780,13 @@ int labrador_ldpc_hip_device_count(void)
 }
 
 const char *labrador_ldpc_hip_last_error(void) { return g_err.c_str(); }
-const char *labrador_ldpc_hip_version(void) { return "labrador_ldpc_hip 0.1.0 (gfx950)"; }
+const char *labrador_ldpc_hip_version(void) { return "labrador_ldpc_hip 0.2.0 (gfx950)"; }
+
+int labrador_ldpc_hip_shard_range(size_t batch, size_t parts, size_t index, size_t *first, size_t *count)
+{
+    if (parts == 0 || index >= parts || !first || !count) return LABRADOR_LDPC_HIP_EINVAL;
+    shard_range(batch, parts, index, first, count);
+    return LABRADOR_LDPC_HIP_OK;
+}
 
 }  // extern "C"
