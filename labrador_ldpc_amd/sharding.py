@@ -3,10 +3,18 @@
 Codewords are independent (the reference keeps no state across calls, src/lib.rs:15-17), so a
 batch splits into contiguous per-rank slices with NO data-path collective; the only cross-rank
 traffic is the timing/counter reduction below (what perftest aggregates through one AtomicU64,
-perftest/src/main.rs:43).  Backend-agnostic: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests."""
+perftest/src/main.rs:43), done host-side over a gloo group: the path needs no RCCL.
+
+One process per GPU.  `spawn_local_ranks` starts them when no launcher did (bench.py --gpus N);
+under `python -m torch.distributed.run` the launcher's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are
+used as they are.  This module imports nothing that touches a GPU."""
 from __future__ import annotations
 
-from typing import Sequence, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -21,6 +29,70 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
 def frame_seed(base_seed: int, rank: int) -> int:
     """Per-rank 64-bit seed: frames of different ranks use disjoint generator streams."""
     return (base_seed & 0xFFFFFFFFFF) | ((rank & 0xFFFFFF) << 40)
+
+
+def spawn_local_ranks(argv: List[str], n: int, env: Optional[Dict[str, str]] = None, timeout: Optional[float] = None) -> int:
+    """Run `python argv...` as n rank processes of one node (RANK = LOCAL_RANK = 0..n-1, WORLD_SIZE = n,
+    rendezvous on 127.0.0.1 at a free port) and return the worst exit status.  The caller must not have
+    initialised a GPU; the children are fresh interpreters.  If a rank fails the others are stopped
+    (by PID)."""
+    if n < 1:
+        raise ValueError("n must be >= 1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    import time
+    deadline = None if timeout is None else time.monotonic() + timeout
+    worst, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 1)
+                for q in live:                   # one rank failed: the others would wait at the barrier for ever
+                    q.terminate()
+        if deadline is not None and time.monotonic() > deadline:
+            for q in live:
+                q.kill()
+            worst = worst or 124
+            deadline = None
+        time.sleep(0.05)
+    return worst
+
+
+def init_ranks() -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the launcher's environment; with world > 1 joins the gloo group
+    used for the barrier and the timing reduction (CPU tensors: no device, no RCCL)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier() -> None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def finish_ranks() -> None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def reduce_max(values: Sequence[float], device=None) -> Sequence[float]:

@@ -23,9 +23,18 @@ def build(force: bool = False) -> str:
     return ORACLE_LIB
 
 
-def _load():
-    build()
-    L = ctypes.CDLL(ORACLE_LIB)
+def build_native() -> str:
+    """The same sources built -O3 -march=native ON THIS HOST (oracle/Makefile target `native`), for
+    bench.py's cpu_baseline leg only; the portable build stays the one the tests check against."""
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "native"])     # -B: never trust a copy built on another host
+    return os.path.join(ORACLE_DIR, "libldpc_oracle_native.so")
+
+
+def _load(path=None):
+    if path is None:
+        build()
+        path = ORACLE_LIB
+    L = ctypes.CDLL(path)
     for f in ("code_n", "code_k", "code_punctured_bits", "code_submatrix_size", "code_circulant_size",
               "code_paritycheck_sum", "bf_working_len", "ms_working_len", "ms_working_u8_len", "output_len"):
         fn = getattr(L, "oracle_" + f)
@@ -121,8 +130,9 @@ def decode_erasures(code, codeword_np: np.ndarray, maxiters: int):
     return bool(ok), int(it.value), cw
 
 
-def decode_ms_batch(code, llrs: np.ndarray, maxiters: int, nthreads: int = 0):
-    """[batch, n] -> (output[batch, output_len], iters[batch] u32, success[batch] u8, threads used)."""
+def decode_ms_batch(code, llrs: np.ndarray, maxiters: int, nthreads: int = 0, lib=None):
+    """[batch, n] -> (output[batch, output_len], iters[batch] u32, success[batch] u8, threads used).
+    `lib`: an alternative build of the oracle loaded with _load(path) (bench.py's native build)."""
     code = int(code)
     llrs = np.ascontiguousarray(llrs)
     assert llrs.ndim == 2 and llrs.shape[1] == n(code)
@@ -131,7 +141,7 @@ def decode_ms_batch(code, llrs: np.ndarray, maxiters: int, nthreads: int = 0):
     out = np.zeros((B, output_len(code)), dtype=np.uint8)
     iters = np.zeros(B, dtype=np.uint32)
     succ = np.zeros(B, dtype=np.uint8)
-    used = getattr(L, "oracle_decode_ms_batch_" + s)(code, llrs.ctypes.data, out.ctypes.data, iters.ctypes.data,
+    used = getattr(lib or L, "oracle_decode_ms_batch_" + s)(code, llrs.ctypes.data, out.ctypes.data, iters.ctypes.data,
                                                      succ.ctypes.data, B, maxiters, nthreads)
     assert used > 0
     return out, iters, succ, used

