@@ -192,6 +192,14 @@ bool labrador_ldpc_decode_ms_f32(enum labrador_ldpc_code code, const float   *ll
 bool labrador_ldpc_decode_ms_f64(enum labrador_ldpc_code code, const double  *llrs, uint8_t *output,
                                  double  *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
 
+/* decode_ms::<i32> (src/decoder.rs:60-68): the crate's generic accepts i32 LLRs; the reference's C API does
+ * not export it (capi/src/lib.rs:97-127 stops at i8/i16/f32/f64).  Same contract as the four above, with the
+ * i32 forms of the LLR helpers below and labrador_ldpc_decode_ms_batch_i32 in part 2. */
+bool labrador_ldpc_decode_ms_i32(enum labrador_ldpc_code code, const int32_t *llrs, uint8_t *output,
+                                 int32_t *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
+void labrador_ldpc_hard_to_llrs_i32(enum labrador_ldpc_code code, const uint8_t *input, int32_t *llrs);
+void labrador_ldpc_llrs_to_hard_i32(enum labrador_ldpc_code code, const int32_t *llrs, uint8_t *output);
+
 /* capi/include/labrador_ldpc.h:219-226  (capi/src/lib.rs:129-153; src/decoder.rs:484-493) */
 void labrador_ldpc_hard_to_llrs_i8 (enum labrador_ldpc_code code, const uint8_t *input, int8_t  *llrs);
 void labrador_ldpc_hard_to_llrs_i16(enum labrador_ldpc_code code, const uint8_t *input, int16_t *llrs);
@@ -259,6 +267,10 @@ int labrador_ldpc_decode_ms_batch_i8 (enum labrador_ldpc_code code, const int8_t
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
 int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output,
+                                      uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts);
+/* i32 (src/decoder.rs:60-68): saturating 32-bit integer arithmetic on the GPU. */
+int labrador_ldpc_decode_ms_batch_i32(enum labrador_ldpc_code code, const int32_t *llrs, uint8_t *output,
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
 /* f64: same results contract; a general (untuned) kernel that keeps the per-edge messages in a

@@ -55,19 +55,23 @@ SYMBOLS = {
     "labrador_ldpc_decode_bf": (_c.c_bool, [_int, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
     "labrador_ldpc_decode_ms_i8": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
     "labrador_ldpc_decode_ms_i16": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
+    "labrador_ldpc_decode_ms_i32": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
     "labrador_ldpc_decode_ms_f32": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
     "labrador_ldpc_decode_ms_f64": (_c.c_bool, [_int, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)]),
     "labrador_ldpc_hard_to_llrs_i8": (None, [_int, _vp, _vp]),
     "labrador_ldpc_hard_to_llrs_i16": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_hard_to_llrs_i32": (None, [_int, _vp, _vp]),
     "labrador_ldpc_hard_to_llrs_f32": (None, [_int, _vp, _vp]),
     "labrador_ldpc_hard_to_llrs_f64": (None, [_int, _vp, _vp]),
     "labrador_ldpc_llrs_to_hard_i8": (None, [_int, _vp, _vp]),
     "labrador_ldpc_llrs_to_hard_i16": (None, [_int, _vp, _vp]),
+    "labrador_ldpc_llrs_to_hard_i32": (None, [_int, _vp, _vp]),
     "labrador_ldpc_llrs_to_hard_f32": (None, [_int, _vp, _vp]),
     "labrador_ldpc_llrs_to_hard_f64": (None, [_int, _vp, _vp]),
     "labrador_ldpc_decode_ms_batch_f32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i8": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i16": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    "labrador_ldpc_decode_ms_batch_i32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_f64": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_bf_batch": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_encode_batch": (_int, [_int, _vp, _vp, _sz, _optp]),
@@ -144,7 +148,7 @@ def _check(status: int) -> None:
 
 
 _NP_SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.int8): "i8", np.dtype(np.int16): "i16",
-              np.dtype(np.float64): "f64"}
+              np.dtype(np.int32): "i32", np.dtype(np.float64): "f64"}
 
 
 def _is_torch(x) -> bool:
@@ -158,7 +162,7 @@ def _ptr(a) -> int:
 def _suffix(a) -> str:
     if _is_torch(a):
         import torch
-        return {torch.float32: "f32", torch.int8: "i8", torch.int16: "i16", torch.float64: "f64"}[a.dtype]
+        return {torch.float32: "f32", torch.int8: "i8", torch.int16: "i16", torch.int32: "i32", torch.float64: "f64"}[a.dtype]
     return _NP_SUFFIX[a.dtype]
 
 

@@ -668,6 +668,11 @@ bool labrador_ldpc_decode_ms_i16(enum labrador_ldpc_code c, const int16_t *llrs,
 {
     return decode_one<int16_t>(c, llrs, output, max_iters, iters_run);
 }
+bool labrador_ldpc_decode_ms_i32(enum labrador_ldpc_code c, const int32_t *llrs, uint8_t *output, int32_t *, uint8_t *,
+                                 size_t max_iters, size_t *iters_run)
+{
+    return decode_one<int32_t>(c, llrs, output, max_iters, iters_run);
+}
 bool labrador_ldpc_decode_ms_f32(enum labrador_ldpc_code c, const float *llrs, uint8_t *output, float *, uint8_t *,
                                  size_t max_iters, size_t *iters_run)
 {
@@ -682,10 +687,12 @@ bool labrador_ldpc_decode_ms_f64(enum labrador_ldpc_code c, const double *llrs, 
 // ---- LLR helpers: capi/src/lib.rs:129-179 ------------------------------------------------------
 void labrador_ldpc_hard_to_llrs_i8(enum labrador_ldpc_code c, const uint8_t *in, int8_t *llrs) { hard_to_llrs(c, in, llrs); }
 void labrador_ldpc_hard_to_llrs_i16(enum labrador_ldpc_code c, const uint8_t *in, int16_t *llrs) { hard_to_llrs(c, in, llrs); }
+void labrador_ldpc_hard_to_llrs_i32(enum labrador_ldpc_code c, const uint8_t *in, int32_t *llrs) { hard_to_llrs(c, in, llrs); }
 void labrador_ldpc_hard_to_llrs_f32(enum labrador_ldpc_code c, const uint8_t *in, float *llrs) { hard_to_llrs(c, in, llrs); }
 void labrador_ldpc_hard_to_llrs_f64(enum labrador_ldpc_code c, const uint8_t *in, double *llrs) { hard_to_llrs(c, in, llrs); }
 void labrador_ldpc_llrs_to_hard_i8(enum labrador_ldpc_code c, const int8_t *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
 void labrador_ldpc_llrs_to_hard_i16(enum labrador_ldpc_code c, const int16_t *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
+void labrador_ldpc_llrs_to_hard_i32(enum labrador_ldpc_code c, const int32_t *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
 void labrador_ldpc_llrs_to_hard_f32(enum labrador_ldpc_code c, const float *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
 void labrador_ldpc_llrs_to_hard_f64(enum labrador_ldpc_code c, const double *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
 
@@ -707,6 +714,13 @@ int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code c, const int16_t *
                                       const struct labrador_ldpc_hip_opts *opts)
 {
     return decode_batch<int16_t>(c, llrs, output, iters, success, batch, max_iters, opts);
+}
+
+int labrador_ldpc_decode_ms_batch_i32(enum labrador_ldpc_code c, const int32_t *llrs, uint8_t *output, uint32_t *iters,
+                                      uint8_t *success, size_t batch, size_t max_iters,
+                                      const struct labrador_ldpc_hip_opts *opts)
+{
+    return decode_batch<int32_t>(c, llrs, output, iters, success, batch, max_iters, opts);
 }
 
 // ---- batched encoder ------------------------------------------------------------------------------

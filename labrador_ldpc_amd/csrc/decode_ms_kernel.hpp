@@ -367,6 +367,46 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
 template <> struct Ops<int8_t>  : IntOps<int8_t, -128, 127> {};
 template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
 
+// i32 LLRs (decoder.rs:60-68): genuine 32-bit integer arithmetic -- the f32 pipeline is exact only to 2^24.
+// Saturating add/sub are v_add_i32 / v_sub_i32 with the clamp bit, saturating_abs is max(x, 0 -sat x)
+// (|INT_MIN| = INT_MAX, :64), minima are v_min3_i32 on magnitudes computed once per message (the compiler
+// shares them).  "Negative" is bit 31, so the sign-word machinery applies unchanged.  The LDS element is a
+// 4-byte container (float) holding the integer's bits, which lets the pair kernel's 64-bit accesses carry it.
+template <> struct Ops<int32_t> {
+    using R = int;
+    using E = float;
+    LDPC_DEV static R zero() { return 0; }
+    LDPC_DEV static R maxval() { return 0x7FFFFFFF; }                           // :63
+    LDPC_DEV static R load(int32_t x) { return x; }
+    LDPC_DEV static float store(R x) { return __int_as_float(x); }
+    LDPC_DEV static R from_lds(float x) { return __float_as_int(x); }
+    LDPC_DEV static int bits(R x) { return x; }
+    LDPC_DEV static R add(R a, R b) { R d; asm("v_add_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // :65
+    LDPC_DEV static R sub(R a, R b) { R d; asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // :66
+    LDPC_DEV static R mag(R x) { const R n = sub(0, x); return n > x ? n : x; }  // :64
+    template <bool AX, bool AY>
+    LDPC_DEV static R min2(R x, R y)
+    {
+        const R a = AX ? mag(x) : x, b = AY ? mag(y) : y;
+        return b < a ? b : a;
+    }
+    template <bool AX> LDPC_DEV static R min2_cap(R x) { return AX ? mag(x) : x; }          // magnitudes never exceed maxval
+    template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<AX, AY>(x, y); }
+    template <bool AX, bool AY, bool AZ>
+    LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
+    template <bool FULL_EXEC>
+    LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
+    {
+        return (old != 0 && ((nv ^ old) < 0)) ? 0 : nv;
+    }
+    // m >= 0 negated when the product of the other edges' signs is negative (:398-405)
+    LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
+    {
+        const int k = (s_all ^ s_own) >> 31;                                     // 0 or -1
+        return (m ^ k) - k;
+    }
+};
+
 // e[i] = min(maxval, min over j != i of a[j]).  Equals what decoder.rs:391-395 selects from
 // (min1, min2): min2 if |v_i| is a smallest magnitude of the check, min1 otherwise -- and
 // min1/min2 start at maxval (decoder.rs:414-415) and are only replaced by strictly smaller
@@ -493,7 +533,7 @@ LDPC_DEV int pi_dev(int i, int j)
 template <int CODE, class T, int IPT, bool PF, int LEAN, int JW>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                             uint32_t batch, uint32_t maxiters, char *lds, char *stage)
+                             uint32_t batch, uint32_t maxiters, float nocap_limit, char *lds, char *stage)
 {
     using GEO = Geometry<CODE, T, IPT>;
     using O = Ops<T>;
@@ -569,7 +609,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
     // f32, one codeword per workgroup: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415)
     // can only bite if some magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums
-    // overflow.  With every |LLR| <= 2^100 nothing does, and the check phase runs without the clamp
+    // overflow.  With every |LLR| <= nocap_limit (a bound the host derives from max_iters, see
+    // nocap_limit_for() in decode_ms_launch.hpp) nothing can, and the check phase runs without the clamp
     // operations (TM8192 pair kernel +3 %).  The vote is one LDS word per codeword (the split-barrier
     // counter's, unused then).
     // Measured: TM2048 41.3 -> 43.0 M codewords/s; TM6144 -1.6 %, TM1536 -0.7 %, TM1280 -11 %, and 34 spilled VGPRs
@@ -725,7 +766,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             bool big = false;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 static_for<0, NTX>([&](auto C_) LDPC_INLINE {
-                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= 0x1p100f);   // NaN counts as big
+                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= nocap_limit);   // NaN counts as big
                 });
             });
             if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
@@ -1188,7 +1229,7 @@ template <int CODE, class T, int IPT, bool PF, int LEAN>
 __global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                 uint32_t batch, uint32_t maxiters)
+                 uint32_t batch, uint32_t maxiters, float nocap_limit)
 {
     using GEO = Geometry<CODE, T, IPT>;
     constexpr int Q = GEO::M / 4;
@@ -1202,17 +1243,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // arrivals of the whole workgroup, whichever copy a wave runs).
     if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
         else
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
     } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
         const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
-        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
-        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
-        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
-        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
     } else {
-        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, lds, stage);
+        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
     }
 }
 

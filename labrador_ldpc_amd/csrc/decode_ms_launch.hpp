@@ -5,6 +5,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 
 #include "decode_ms_kernel.hpp"
@@ -19,22 +20,39 @@ template <class T>
 hipError_t launch_decode_ms(int code, int variant, const T *llrs, uint8_t *output, uint32_t *iters,
                             uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
 
+// Largest |LLR| for which the f32 kernels may drop the FLT_MAX clamp of the exclusive minimum
+// (decoder.rs:414-415) for a run of `maxiters` iterations.  The clamp acts only if a magnitude overflows to
+// infinity.  With L = max |LLR|, V_k = max |v| and U_k = max |u| after iteration k:  U_k <= V_k (an exclusive
+// minimum is one of the other |v|),  |va| <= L + 6 U_k (variable degree <= 6 in every code),
+// |v| = |va - u| <= L + 7 U_k,  hence  V_k <= L (1 + 7 + ... + 7^k) < L 7^(k+1) / 6  and every sum stays below
+// L * 7^maxiters * 1.4 (rounding included).  Requiring that to stay under 2^127 gives the limit below:
+// 2^55 at the benchmark's 25 iterations, less than any real LLR from 45 iterations on (then every codeword
+// simply takes the clamped copy of the loop).  0 = never.
+inline float nocap_limit_for(uint32_t maxiters)
+{
+    const double log2_limit = 126.0 - 2.8074 * (double)maxiters;      // log2(7) = 2.80735...
+    if (log2_limit < -120.0) return 0.0f;
+    return (float)__builtin_ldexp(1.0, (int)__builtin_floor(log2_limit));
+}
+
 // Resident workgroups per device for one instantiation (occupancy x compute units), cached.
 template <int CODE, class T, int IPT, bool PF, int LEAN>
 int resident_workgroups()
 {
     using GEO = Geometry<CODE, T, IPT>;
-    static int cached[64] = {};
+    static std::atomic<int> cached[64] = {};     // concurrent callers may both fill an entry: they store the same value
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev] == 0) {
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF, LEAN>, GEO::WG, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached[dev] = per_cu * cus;
+        v = per_cu * cus;
+        cached[dev].store(v, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return v;
 }
 
 // Launch one instantiation (IPT indices per thread; LEAN 1 = register-lean check phase, 2 = in-place messages).
@@ -49,7 +67,7 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     constexpr bool PF = false;
     if (batch == 0) return hipSuccess;
     const size_t groups = (batch + GEO::G - 1) / GEO::G;
-    if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (batch > 0xFFFFFFFFull || groups > 0x7FFFFFFFull) return hipErrorInvalidValue;   // (capi.hip slices larger batches)
     // Persistent workgroups with a static stride over the codeword groups.  Where one workgroup
     // fills a CU (TM8192) the grid is exactly the resident set: each workgroup then decodes
     // hundreds of codewords and the data-dependent iteration counts average out.  Where several
@@ -59,7 +77,7 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     size_t grid = resident <= 256 ? resident : resident * 16;
     if (grid > groups) grid = groups;
     hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
-                       llrs, output, iters, success, (uint32_t)batch, maxiters);
+                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters));
     return hipGetLastError();
 }
 
@@ -70,7 +88,7 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
     // is TM5120 only (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB).  Measured slower
     // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
-    constexpr int LEAN = CODE == TM5120 && IPT == 1 ? 1 : 0;
+    constexpr int LEAN = CODE == TM5120 && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
     return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream);
 }
 
@@ -83,19 +101,21 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
     using GEO = PairGeometry<CODE, T>;
     if (batch == 0) return hipSuccess;
     if (batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    static int cached[64] = {};
+    static std::atomic<int> cached[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev] == 0) {
+    int resident = cached[dev].load(std::memory_order_relaxed);
+    if (resident == 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_pair_kernel<CODE, T>, GEO::NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached[dev] = per_cu * cus;
+        resident = per_cu * cus;
+        cached[dev].store(resident, std::memory_order_relaxed);
     }
-    size_t grid = cached[dev] <= 256 ? (size_t)cached[dev] : (size_t)cached[dev] * 16;
+    size_t grid = resident <= 256 ? (size_t)resident : (size_t)resident * 16;
     if (grid > batch) grid = batch;
     hipLaunchKernelGGL((decode_ms_pair_kernel<CODE, T>), dim3((unsigned)grid), dim3(GEO::NT), 0, stream,
-                       llrs, output, iters, success, (uint32_t)batch, maxiters);
+                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters));
     return hipGetLastError();
 }
 

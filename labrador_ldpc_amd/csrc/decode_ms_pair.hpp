@@ -31,7 +31,7 @@
 #define LDPC_PAIR_LOCAL_IN_VAR -1
 #endif
 // f32: run the check phase without the FLT_MAX clamp of the exclusive minimum when no LLR of the codeword
-// exceeds 2^100 in magnitude (see begin_codeword): 6.84 -> 7.05.
+// exceeds nocap_limit in magnitude (see begin_codeword): 6.84 -> 7.05.
 #ifndef LDPC_PAIR_NOCAP
 #define LDPC_PAIR_NOCAP 1
 #endif
@@ -126,7 +126,7 @@ constexpr bool all_exchanged_are_pi(const Prototype &p)
 template <int CODE, class T, int JW>
 LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                                   uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                                  uint32_t batch, uint32_t maxiters, char *lds)
+                                  uint32_t batch, uint32_t maxiters, float nocap_limit, char *lds)
 {
     using GEO = PairGeometry<CODE, T>;
     using O = Ops<T>;
@@ -211,13 +211,14 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         if (t < 2) flag_at(t) = 0;
         // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
         // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
-        // |LLR| <= 2^100 nothing does (|va| <= 7 * 2^100), and the check phase runs without the clamp
-        // operations (8 of 76 min-class instructions per thread and iteration).
+        // |LLR| <= nocap_limit (derived from max_iters by the host: nocap_limit_for(), decode_ms_launch.hpp)
+        // nothing can, and the check phase runs without the clamp operations (8 of 76 min-class
+        // instructions per thread and iteration).
         if constexpr (NOCAP_POSSIBLE) {
             bool big = false;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 static_for<0, NTX>([&](auto C_) LDPC_INLINE {
-                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= 0x1p100f);   // NaN counts as big
+                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= nocap_limit);   // NaN counts as big
                 });
             });
             if (__ballot(big) != 0 && (t & 63) == 0) cap_flag() = 1;
@@ -507,16 +508,16 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 template <int CODE, class T>
 __global__ void __launch_bounds__((PairGeometry<CODE, T>::NT))
 decode_ms_pair_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters_out,
-                      uint8_t *__restrict__ success_out, uint32_t batch, uint32_t maxiters)
+                      uint8_t *__restrict__ success_out, uint32_t batch, uint32_t maxiters, float nocap_limit)
 {
     using GEO = PairGeometry<CODE, T>;
     __shared__ __attribute__((aligned(16))) char lds[GEO::LDS_BYTES];
     constexpr int qmap[4] = LDPC_PAIR_QMAP;
     const int jw = qmap[__builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8)];   // quarter of this wave's indices
-    if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, lds);
-    else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, lds);
-    else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, lds);
-    else decode_ms_pair_body<CODE, T, 3>(llrs, output, iters_out, success_out, batch, maxiters, lds);
+    if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
+    else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
+    else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
+    else decode_ms_pair_body<CODE, T, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
 }
 
 }  // namespace ldpc

@@ -24,7 +24,7 @@ def _compare(code, llrs, maxiters, variant=0):
 
 
 @pytest.mark.parametrize("code", ALL, ids=lambda c: c.name)
-@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16, np.float64], ids=["f32", "i8", "i16", "f64"])
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.int16, np.int32, np.float64], ids=["f32", "i8", "i16", "i32", "f64"])
 def test_three_flip_scenario(code, dtype):
     """test_decode_ms of the reference (src/decoder.rs:671-699): 3 flipped bits, +-1 LLRs, 50 iters."""
     cw = oracle.copy_encode(code, np.arange(code.k() // 8, dtype=np.uint8))
@@ -51,6 +51,23 @@ def test_awgn_parity(code, dtype):
         llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, dtype, scale=scale, lim=lim)
         it, ok = _compare(code, llrs, 25)
     assert ok.any()
+
+
+@pytest.mark.parametrize("code", ALL, ids=lambda c: c.name)
+def test_i32_parity(code):
+    """decode_ms::<i32> (src/decoder.rs:60-68): genuine 32-bit saturating arithmetic on the GPU.  Scales from a few
+    units (many exact ties and zeros) to LLRs at +-2^31 (every accumulation saturates; |INT_MIN| = INT_MAX, :64)."""
+    rng = np.random.default_rng(0x132 + int(code))
+    frames = 48 if code.n() >= 5120 else 128
+    for ebn0, scale in ((2.5, 3.0), (2.0, 1000.0), (3.0, 2.0 ** 24 + 1), (2.5, 3e8), (2.0, 1.5e9), (1.0, 4e9)):
+        llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0 + (1.5 if code.n() <= 1280 else 0.0), np.int32, scale=scale, lim=2 ** 31 - 1)
+        if scale > 1e9:
+            llrs[llrs == -(2 ** 31 - 1)] = -2 ** 31
+        _compare(code, llrs, 25)
+    llrs[:] = np.where(rng.random(llrs.shape) < 0.5, 2 ** 31 - 1, -2 ** 31).astype(np.int32)
+    _compare(code, llrs, 6)
+    for variant in ((2, 32) if code == LDPCCode.TM8192 else ()):
+        _compare(code, llrs, 6, variant=variant)
 
 
 @pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TC512, LDPCCode.TM1280, LDPCCode.TM2048, LDPCCode.TM8192],
@@ -177,7 +194,7 @@ def test_tm8192_ragged_batches_on_the_pair_kernel():
 
 def test_tm8192_clamp_mode_is_chosen_per_codeword():
     """The f32 pair kernel drops the FLT_MAX clamp of the exclusive minimum for codewords whose LLRs are all
-    <= 2^100 in magnitude and keeps it for the others; a persistent workgroup decodes both kinds back to back
+    below a limit derived from max_iters (2^69 at 20 iterations) and keeps it for the others; a persistent workgroup decodes both kinds back to back
     (frames f, f + 256, f + 512 share a workgroup on an MI355X)."""
     code = LDPCCode.TM8192
     rng = np.random.default_rng(99)
@@ -190,7 +207,7 @@ def test_tm8192_clamp_mode_is_chosen_per_codeword():
         elif kind == 2:
             llrs[f] *= np.float32(1e37)                     # sums overflow to +-inf
         elif kind == 3:
-            llrs[f, ::97] = np.float32(2.0 ** 100)          # the largest LLR that still takes the clamp-free path
+            llrs[f, ::97] = np.float32(2.0 ** 64)           # large, but under the clamp-free path's limit at 20 iterations (2^69)
     _compare(code, llrs, 20)
 
 
@@ -208,3 +225,22 @@ def test_tm2048_clamp_mode_is_chosen_per_codeword():
         elif kind == 1:
             llrs[f] *= np.float32(1e37)
     _compare(code, llrs, 15)
+
+
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048], ids=lambda c: c.name)
+def test_clamp_free_path_at_its_magnitude_limit(code):
+    """the clamp-free check phase is exact only while no magnitude reaches FLT_MAX, and messages feed
+    back, so the admissible |LLR| depends on the iteration count: the host passes 2^floor(126 - log2(7) max_iters)
+    (nocap_limit_for, decode_ms_launch.hpp).  Frames with EVERY |LLR| at that limit, random signs, never
+    converging, must agree with the oracle (whose minima start at FLT_MAX) at every max_iters -- on the
+    clamp-free copy of the loop up to the limit, on the clamped copy just above it and beyond 45 iterations."""
+    rng = np.random.default_rng(64)
+    signs = np.where(rng.random((24, code.n())) < 0.5, 1.0, -1.0).astype(np.float32)
+    for maxiters in (5, 20, 25, 44, 60, 300):
+        e = int(np.floor(126.0 - 2.8074 * maxiters))
+        for mag in (2.0 ** max(e, -120), 2.0 ** min(max(e, -120) + 1, 127), 2.0 ** 64, 1.0):
+            llrs = signs * np.float32(mag)
+            it, ok = _compare(code, llrs, maxiters)
+            assert (ok == 0).all() and (it == maxiters).all()
+            llrs[:, ::3] *= np.float32(2.0 ** -20)                  # mixed magnitudes
+            _compare(code, llrs, maxiters)
