@@ -42,70 +42,14 @@
 
 #define LDPC_INLINE __attribute__((always_inline))
 
-// Diagnostic switches for tools/kbench.hip only (timing experiments; results are wrong with them).
+#include "decode_ms_tuning.hpp"    // tuned settings; experiment overrides and LDPC_DIAG_* only under LDPC_KBENCH
+
 #ifdef LDPC_DIAG_NOBARRIER
 #define LDPC_SYNC() __builtin_amdgcn_s_waitcnt(0)
 #else
 // Workgroup barrier for LDS hand-offs.  Written out (instead of __syncthreads()) so that it waits
 // for LDS operations only and not for the asynchronous LLR staging copies counted in vmcnt.
 #define LDPC_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
-// Experiment switch: split (arrive / wait) barrier between the variable and the check phase.
-// Measured SLOWER on TM8192 (5.09 vs 5.34 M codewords/s): with it the exchanged marginals can only be
-// requested after the wait, so their latency is no longer covered by the local-edge work.  Off.
-#ifndef LDPC_SPLIT_BARRIER
-#define LDPC_SPLIT_BARRIER 0
-#endif
-// Experiment switch: zero the dropped lanes by EXEC predication (v_cmpx + v_mov) instead of
-// v_cndmask.  Measured SLOWER on TM8192 (4.35 vs 5.34 M codewords/s: EXEC writes stall the VALU). Off.
-#ifndef LDPC_CMPX_SELECT
-#define LDPC_CMPX_SELECT 0
-#endif
-#ifndef LDPC_QUARTER_SPECIALISE
-#define LDPC_QUARTER_SPECIALISE 2
-#endif
-// Experiment switch: issue the next codeword's LLR loads before the current one's epilogue.  Lowers the
-// fixed cost per codeword (1.66 -> 1.26 ms per 131 072 frames at 0 iterations) but the full decode got
-// 1.5 % SLOWER on TM8192 (5.50 vs 5.59 M codewords/s, twice, same process): register allocation of the
-// main loop changes.  Off.
-#ifndef LDPC_EARLY_FETCH
-#define LDPC_EARLY_FETCH 0
-#endif
-// Experiment switch: ds_write_addtid_b32 for the stores of the marginals (see lds_store_own): half the
-// LDS cycles of ds_write_b32.  +1 % on TM8192 (6.09 -> 6.15 M codewords/s), but the instruction's base
-// register M0 holds 16 bits, so it is only correct while the workgroup's LDS allocation starts below
-// 64 KB -- true for a lone TM8192 workgroup, false as soon as several workgroups (or another kernel)
-// share the CU (TM2048 decoded wrongly).  Off.
-// f32: clamp-free check phase for codewords whose LLRs are bounded (see NOCAP_POSSIBLE in the kernel body).
-#ifndef LDPC_NOCAP
-#define LDPC_NOCAP 1
-#endif
-#ifndef LDPC_LOCAL_IN_VAR
-#define LDPC_LOCAL_IN_VAR -1       // -1 = per kernel (local_in_var_default), >= 0 forces the count (experiments)
-#endif
-#ifndef LDPC_ADDTID
-#define LDPC_ADDTID 0
-#endif
-// Progress-based wave priority.  VALU issue is arbitrated by priority, then age, so the oldest wave
-// of a SIMD runs ahead and the youngest arrives last at every barrier, the last stretch of each
-// phase with the SIMD half empty.  Lowering a wave's priority as it advances through a phase
-// lets the laggards catch up.  The schedule that measured best keeps priority 3 through the edge
-// updates and steps down over the last check rows (LDPC_PRIO_ROWS; a sweep of a dozen schedules spans
-// 6.06-6.40 M codewords/s on TM8192, the inverted one 5.54): TM8192 5.61 -> 6.40, TM6144 9.64 ->
-// 10.83, TM2048 46.9 -> 48.1, TM5120 13.76 -> 14.02 M codewords/s.  Only for codewords of 8 or more waves
-// (PRIO_WAVES below): with one or two waves per codeword it costs (TC512 -7 %, TM1280 -1 %).
-// 0 = off, 1 = with a scheduling barrier at each step, 2 = plain.
-#ifndef LDPC_PRIO
-#define LDPC_PRIO 2
-#endif
-#ifndef LDPC_PRIO_ROWS
-#define LDPC_PRIO_ROWS {2, 2, 1, 1, 1, 0}   // priority during the last six (index, check row) steps of the check phase
-#endif
-#ifndef LDPC_PRIO_ROWS_LEAN
-#define LDPC_PRIO_ROWS_LEAN {3, 3, 3, 2, 1, 0}   // the same for the register-lean check phase
-#endif
-#ifndef LDPC_PRIO_VAR
-#define LDPC_PRIO_VAR 2          // priority of the first half of the (short) variable phase
 #endif
 #if LDPC_PRIO == 1
 #define LDPC_SETPRIO(n) do { if constexpr (PRIO_WAVES) { __builtin_amdgcn_s_setprio(n); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -272,22 +216,10 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
         const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
         return __int_as_float(t) < 0.0f;
     }
-    // nv, or +0 where drop(nv, old).  With all lanes active (FULL_EXEC) the select is done by
-    // predication -- v_cmpx writes EXEC, a v_mov zeroes the dropped lanes, EXEC is restored --
-    // because v_mov issues at the fast VALU rate and v_cndmask does not (tools/ubench).
+    // nv, or +0 where drop(nv, old)  (zeroing by EXEC predication instead of v_cndmask measured slower:
+    // EXEC writes stall the VALU -- DESIGN.md 4.4)
     template <bool FULL_EXEC>
-    LDPC_DEV static R self_correct(R nv, R old)
-    {
-#if LDPC_CMPX_SELECT
-        if constexpr (FULL_EXEC) {
-            const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
-            R nw = nv;
-            asm("v_cmpx_gt_f32_e32 vcc, 0, %1\n\tv_mov_b32_e32 %0, 0\n\ts_mov_b64 exec, -1" : "+v"(nw) : "v"(t) : "vcc");
-            return nw;
-        }
-#endif
-        return select_zero(drop(nv, old), nv);
-    }
+    LDPC_DEV static R self_correct(R nv, R old) { return select_zero(drop(nv, old), nv); }
     // m >= 0 has bit 31 clear, so "m with sign s_all ^ s_own" is one three-input XOR of sign words
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
@@ -591,19 +523,6 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     auto lds_load = [&](int byte_off) LDPC_INLINE -> E { return lds_at(byte_off); };
     auto lds_store = [&](int byte_off, E val) LDPC_INLINE { lds_at(byte_off) = val; };
 #endif
-    // Store to the thread's OWN position of a block region: ds_write_addtid_b32 takes its address from
-    // M0 + offset + 4 * lane -- no address VGPR to send, 2 LDS cycles per wave instead of 4
-    // (MI355X_MICROARCH.md, LDS).  The compiler does not use M0 in this kernel.
-    constexpr bool ADDTID = LDPC_ADDTID && G == 1 && NT >= 64 && SZ == 4;
-    unsigned wave_lds = 0;                        // LDS byte address of the wave's first lane in block region 0
-    if constexpr (ADDTID)
-        wave_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(__attribute__((address_space(3))) char *)gbase + (unsigned)(t & ~63) * SZ));
-    auto lds_store_own = [&](auto OFF_, E val) LDPC_INLINE {      // OFF_: literal byte offset of index (S * NT + 0)
-        constexpr int off = decltype(OFF_)::value;
-        static_assert(off >= 0 && off < 65536, "ds offset field");
-        const unsigned m0v = wave_lds;            // (named so that the generic lambda captures it)
-        asm volatile("s_mov_b32 m0, %1\n\tds_write_addtid_b32 %0 offset:%2" ::"v"(val), "s"(m0v), "n"(off) : "memory");
-    };
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
@@ -611,33 +530,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // can only bite if some magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums
     // overflow.  With every |LLR| <= nocap_limit (a bound the host derives from max_iters, see
     // nocap_limit_for() in decode_ms_launch.hpp) nothing can, and the check phase runs without the clamp
-    // operations (TM8192 pair kernel +3 %).  The vote is one LDS word per codeword (the split-barrier
-    // counter's, unused then).
+    // operations (TM8192 pair kernel +3 %).  The vote is one LDS word per codeword.
     // Measured: TM2048 41.3 -> 43.0 M codewords/s; TM6144 -1.6 %, TM1536 -0.7 %, TM1280 -11 %, and 34 spilled VGPRs
     // with two indices per thread (the second copy of the loop is not free), hence TM2048 only.
-    constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && CODE == TM2048 && G == 1 && LEAN == 0 && IPT == 1 && !(LDPC_SPLIT_BARRIER);
+    constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && CODE == TM2048 && G == 1 && LEAN == 0 && IPT == 1;
     auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(gbase + FLAG_OFF + 8); };
-
-    // Split barrier between the variable and the check phase (single-codeword workgroups): a
-    // wave ARRIVES (LDS counter) as soon as its marginals are stored, updates its local edges,
-    // and only then WAITS for the other waves -- the arrival skew that a plain s_barrier turns
-    // into idle time is spent on work that needs no exchanged data.  LDS operations of a wave
-    // execute in order, so the counter add needs no wait for the stores before it.
-    constexpr bool SPLIT = LDPC_SPLIT_BARRIER && G == 1 && NT >= 128;
-    constexpr int NWAVES = NT / 64 > 0 ? NT / 64 : 1;
-    const int cnt_addr = (int)(size_t)(__attribute__((address_space(3))) char *)(gbase + FLAG_OFF + 8);
-    auto arrive = [&]() LDPC_INLINE {
-        if ((tid & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_addr), "v"(1) : "memory");
-        else asm volatile("" ::: "memory");
-    };
-    auto wait_arrivals = [&](uint32_t expected) LDPC_INLINE {
-        for (;;) {
-            uint32_t c;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(cnt_addr) : "memory");
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)c) >= expected) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
 
     // Byte offset, inside one block's M*SZ-byte LDS region, of the variable that check
     // i = S*NT + t of block B is wired to; `tb` is t*SZ.  Identity blocks rotate the whole
@@ -771,7 +668,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
             if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
         } else {
-            if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;  // split-barrier arrival counter
+            if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;  // (the clamp-vote word, unused here)
         }
     };
 
@@ -866,8 +763,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int cs = col_slot(P, C);
                 if constexpr (cs >= 0) {
                     constexpr int off = lds_xva_off(P, cs, BLK_BYTES);
-                    if constexpr (ADDTID) lds_store_own(IC<off + S * NT * SZ>{}, O::store(acc));
-                    else lds_store(off + i * SZ, O::store(acc));
+                    lds_store(off + i * SZ, O::store(acc));
                 }
                 }
             });
@@ -904,13 +800,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
         });
         __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
-#ifdef LDPC_PRIO_LOCAL
-        LDPC_SETPRIO(LDPC_PRIO_LOCAL);
-#endif
-        if constexpr (!SPLIT) {
-            check_local();                                                             // (2)
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        check_local();                                                                 // (2)
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
@@ -1105,7 +996,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
     live = cw < batch;
-    if constexpr (!LDPC_EARLY_FETCH) { if (!first) fetch_llrs(cw); }
+    if (!first) fetch_llrs(cw);    // (issuing them before the previous epilogue measured 1.5 % slower here: register allocation)
     begin_codeword(!first);
     if constexpr (PF) {
         // the staged LLRs are in registers (the loads above were waited for by their use in
@@ -1131,13 +1022,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         else { if (__all(done)) break; }
 
         if (G == 1 || !done) variable_phase();
-        if constexpr (SPLIT) {
-            arrive();
-            check_local();
-            wait_arrivals((uint32_t)NWAVES * (it + 1));
-        } else {
-            LDPC_SYNC();
-        }
+        LDPC_SYNC();
         if (it > 0 && t == 0) flag_at(it - 1) = 0;
         if (G == 1 || !done) {
             if constexpr (LEAN == 2) check_phase_inplace(it);
@@ -1152,11 +1037,6 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         else iterate(IC<0>{});
     } else {
         iterate(IC<1>{});
-    }
-
-    if constexpr (!PF && LDPC_EARLY_FETCH) {
-        const uint32_t gn = g + gridDim.x;                   // next codeword of this workgroup, if any
-        if (gn < n_groups) fetch_llrs(G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gn) : gn * G + grp);
     }
 
     // ---- hard decision of the marginals, MSB first (decoder.rs:455-461 / :467-473) ------------
@@ -1206,9 +1086,6 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 // VGPRs so that two workgroups share a CU.  LEAN == 2 ("in place"): additionally the variable thread
 // overwrites each exchanged u with nv = va - u in its LDS slot and publishes only the sign word of the
 // marginals, so that no array of marginals is needed -- f64 TM8192 then fits the LDS (152 KB).
-#ifndef LDPC_TM2048_WAVES
-#define LDPC_TM2048_WAVES 6
-#endif
 // Waves per SIMD the register allocation must leave room for.  The lean variant exists to reach 4
 // (two 512-thread workgroups per CU); TM2048 sits right at the 80-VGPR step between 6 and 5 waves
 // (f32 73, i8/i16 81 VGPRs: three workgroups per CU instead of two, 35 vs 30 M codewords/s for i8).
@@ -1219,9 +1096,6 @@ constexpr int min_waves_per_simd()
     if (LEAN == 1) return 4;
     if (CODE == TM2048 && IPT == 1) return LDPC_TM2048_WAVES;
     if (CODE == TM1280 && IPT == 1) return 3;         // 183 -> 168 VGPRs: f32 28.4 -> 38.6, i8 27.0 -> 34.4 M codewords/s
-#ifdef LDPC_MINW_CODE
-    if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
-#endif
     return 1;
 }
 

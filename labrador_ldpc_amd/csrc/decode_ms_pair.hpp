@@ -22,70 +22,7 @@
 
 #include "decode_ms_kernel.hpp"
 
-// ---- tuned settings (each measured with tools/kbench.hip -DKPAIR=1 on TM8192) --------------------------
-// How many of the thread's local-edge updates (of 14 on TM8192) are done at the end of the variable phase
-// (LDS-bound: the VALU idles there) instead of at the start of the check phase (VALU-bound), where the
-// rest still covers the latency of the marginal reads.  f32 0/3/5/7/9/14 -> 7.04 / 7.07 / 7.24 / 7.41 /
-// 7.32 / 7.26 M codewords/s; i8 0/4/7 -> 9.29 / 9.61 / 8.31.  -1 = per type (7 for f32, 4 else).
-#ifndef LDPC_PAIR_LOCAL_IN_VAR
-#define LDPC_PAIR_LOCAL_IN_VAR -1
-#endif
-// f32: run the check phase without the FLT_MAX clamp of the exclusive minimum when no LLR of the codeword
-// exceeds nocap_limit in magnitude (see begin_codeword): 6.84 -> 7.05.
-#ifndef LDPC_PAIR_NOCAP
-#define LDPC_PAIR_NOCAP 1
-#endif
-// Issue the next codeword's LLR loads before this one's epilogue: the fixed cost per codeword drops from
-// 2.55 to 2.12 us (1.305 -> 1.086 ms per 131 072 frames at 0 iterations), +0.7 % at 25 iterations.
-#ifndef LDPC_PAIR_EARLY_FETCH
-#define LDPC_PAIR_EARLY_FETCH 1
-#endif
-// Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = per type (on for
-// i8/i16: 8.0 -> 9.0; off for f32: 7.05 -> 6.90), 0 / 1 = force.
-#ifndef LDPC_PAIR_ODD_B64
-#define LDPC_PAIR_ODD_B64 -1
-#endif
-// Wave priority (see LDPC_PRIO in decode_ms_kernel.hpp) over the six (check row, index) steps of the check
-// phase; 3 before them.  A dozen alternatives, also per quarter, measured 6.4-6.75 against 6.75 for this one.
-#ifndef LDPC_PRIO_ROWS_PAIR
-#define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}
-#endif
-
-// ---- experiment switches, all measured slower or equal and left off ---------------------------------------
-#ifndef LDPC_PAIR_LOCAL_INTERLEAVED
-#define LDPC_PAIR_LOCAL_INTERLEAVED 0   // the moved local-edge updates after each column instead of after all
-#endif
-#ifndef LDPC_PAIR_SKIP_FIRST
-#define LDPC_PAIR_SKIP_FIRST 0           // iteration 0 without the (all-zero) u reads and slot zeroing: 1.94 vs 2.04 ms per 131 072 frames
-#endif                                   // at one iteration, but the second copy of the variable phase costs 6 % at 25 (7.42 -> 6.94)
-#ifndef LDPC_PAIR_ROWWISE
-#define LDPC_PAIR_ROWWISE 0              // update the exchanged edges row by row, right before the row's minima
-#endif
-#ifndef LDPC_PAIR_RELOAD_LLR
-#define LDPC_PAIR_RELOAD_LLR 0    // re-read the LLRs from L2 every iteration instead of holding 8 VGPRs: 6.63 -> 6.00
-#endif
-#ifndef LDPC_PAIR_LATE_ODD
-#define LDPC_PAIR_LATE_ODD 0      // request the marginals of the odd rotations after the local-edge work: -1 %
-#endif
-#ifndef LDPC_PAIR_QMAP
-#define LDPC_PAIR_QMAP {0, 1, 2, 3}           // which quarter the k-th group of four waves (oldest first) works on
-#endif
-#ifndef LDPC_PAIR_HEAD_Q
-#define LDPC_PAIR_HEAD_Q {3, 3, 3, 3}         // per quarter: priority of the request / edge-update stages
-#endif
-#ifndef LDPC_PAIR_VAR_Q
-#define LDPC_PAIR_VAR_Q {LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR, LDPC_PRIO_VAR}   // ... of the first half of the variable phase
-#endif
-#ifndef LDPC_PAIR_VAR2_Q
-#define LDPC_PAIR_VAR2_Q {0, 0, 0, 0}         // ... of its second half
-#endif
-#ifndef LDPC_PRIO_ROWS_PAIR_Q0                // per quarter: the table above
-#define LDPC_PRIO_ROWS_PAIR_Q0 LDPC_PRIO_ROWS_PAIR
-#define LDPC_PRIO_ROWS_PAIR_Q1 LDPC_PRIO_ROWS_PAIR
-#define LDPC_PRIO_ROWS_PAIR_Q2 LDPC_PRIO_ROWS_PAIR
-#define LDPC_PRIO_ROWS_PAIR_Q3 LDPC_PRIO_ROWS_PAIR
-#endif
-// (also: LDPC_PAIR_TAIL_PRIO = extra priority step inside the last row, LDPC_DIAG_STAMPS = per-phase s_memtime sums)
+// Tuned settings (LDPC_PAIR_*, LDPC_PRIO_ROWS_PAIR): decode_ms_tuning.hpp.
 
 namespace ldpc {
 
@@ -145,10 +82,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
 
-    // logical thread index: waves are handed quarters in the order LDPC_PAIR_QMAP (the kernel wrapper
-    // branches on the same map), everything below sees only t
-    constexpr int qmap[4] = LDPC_PAIR_QMAP;
-    static_assert(qmap[0] + qmap[1] + qmap[2] + qmap[3] == 6, "LDPC_PAIR_QMAP must be a permutation of 0..3");
     const int t = (int)(threadIdx.x & (M / 8 - 1)) + JW * (M / 8);
     __builtin_assume(t >= 0 && t < NT);
     const uint32_t n_groups = batch;
@@ -203,11 +136,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
             static_for<0, NTX>([&](auto C_) LDPC_INLINE { llr[S][decltype(C_)::value] = O::load(lraw[S][decltype(C_)::value]); });
         });
-#if !LDPC_PAIR_SKIP_FIRST
         static_for<0, NX>([&](auto X_) LDPC_INLINE {                                   // u = 0 in every exchange slot
             lds2(lds_xu_off(P, decltype(X_)::value, BLK_BYTES) + tb8) = ldpc_f2{0.0f, 0.0f};
         });
-#endif
         if (t < 2) flag_at(t) = 0;
         // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
         // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
@@ -232,29 +163,16 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
-    auto variable_phase = [&](auto FIRST_) LDPC_INLINE {
-        constexpr bool FIRST = decltype(FIRST_)::value != 0;   // iteration 0: every u is zero, va = llr exactly (llr + 0.0 = llr)
+    auto variable_phase = [&]() LDPC_INLINE {
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
-        {
-            constexpr int var[4] = LDPC_PAIR_VAR_Q;
-            LDPC_SETPRIO(var[JW]);
-        }
+        LDPC_SETPRIO(LDPC_PRIO_VAR);
         static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
             constexpr int C = decltype(C_)::value;
-            if constexpr (C == NCOLS / 2) { constexpr int var2[4] = LDPC_PAIR_VAR2_Q; LDPC_SETPRIO(var2[JW]); }
+            if constexpr (C == NCOLS / 2) LDPC_SETPRIO(0);
             R acc0 = O::zero(), acc1 = O::zero();
-            if constexpr (C < NTX) {
-#if LDPC_PAIR_RELOAD_LLR
-                const T *src = (llrs + (size_t)cw * N) + (unsigned)(C * M);
-                acc0 = O::load(src[2 * (unsigned)tq]);
-                acc1 = O::load(src[2 * (unsigned)tq + 1]);
-#else
-                acc0 = llr[0][C]; acc1 = llr[1][C];
-#endif
-            }
-            if constexpr (!FIRST)
+            if constexpr (C < NTX) { acc0 = llr[0][C]; acc1 = llr[1][C]; }
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int B = decltype(B_)::value;
                 if constexpr (P.blk[B].col == C) {
@@ -273,25 +191,15 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             va[1][C] = acc1;
             constexpr int cs = col_slot(P, C);
             if constexpr (cs >= 0) lds2(lds_xva_off(P, cs, BLK_BYTES) + tb8) = ldpc_f2{O::store(acc0), O::store(acc1)};
-#if LDPC_PAIR_LOCAL_INTERLEAVED
-            static_for<0, IPT>([&](auto S_) LDPC_INLINE {                               // this column's moved local edges right away
-                static_for<0, NB>([&](auto B_) LDPC_INLINE {
-                    constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                    if constexpr (exch_slot(P, B) < 0 && P.blk[B].col == C && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][C]);
-                });
-            });
-#endif
         });
         // the local-edge part of the check update for the first LDPC_PAIR_LOCAL_IN_VAR indices, while the
         // marginal stores drain (this phase is LDS-bound, the check phase VALU-bound)
-#if !LDPC_PAIR_LOCAL_INTERLEAVED
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
             });
         });
-#endif
     };
 
     // ---- check phase (decoder.rs:414-450 and :391-405 of the next iteration) -------------------------
@@ -301,18 +209,13 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
-        {
-            constexpr int head[4] = LDPC_PAIR_HEAD_Q;
-            LDPC_SETPRIO(head[JW]);
-        }
+        LDPC_SETPRIO(3);
         R xs[IPT][NB];
         int ad[IPT][NB];
-        auto request = [&](auto ODD_) LDPC_INLINE {                                    // (1) request the exchanged marginals
-        static_for<0, NB>([&](auto B_) LDPC_INLINE {
+        static_for<0, NB>([&](auto B_) LDPC_INLINE {                                   // (1) request the exchanged marginals
             constexpr int B = decltype(B_)::value;
             constexpr int slot = exch_slot(P, B);
-            constexpr int which = decltype(ODD_)::value;                              // 0 = even rotations, 1 = odd, 2 = all
-            if constexpr (slot >= 0 && (which == 2 || (which == 1) == !even_c(B))) {
+            if constexpr (slot >= 0) {
                 constexpr int cs = col_slot(P, P.blk[B].col);
                 constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                 if constexpr (even_c(B)) {
@@ -337,8 +240,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 }
             }
         });
-        };
-        request(IC<LDPC_PAIR_LATE_ODD ? 0 : 2>{});
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2) local edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
@@ -346,26 +247,20 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) >= LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
             });
         });
-        if constexpr (LDPC_PAIR_LATE_ODD) request(IC<1>{});
         __builtin_amdgcn_sched_barrier(0);
-#if !LDPC_PAIR_ROWWISE
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B]);
             });
         });
-#endif
         static_for<0, NROWS>([&](auto R_) LDPC_INLINE {                                // (4) per check row, both indices
             constexpr int Rw = decltype(R_)::value;
             constexpr int D = row_degree(P, Rw);
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value;
-                {
-                    // one table per quarter: on every SIMD the four waves of a workgroup are one from each
-                    // quarter, oldest = quarter 0, and age is the tie-break of the issue arbitration
-                    constexpr int prio_tab[4][6] = {LDPC_PRIO_ROWS_PAIR_Q0, LDPC_PRIO_ROWS_PAIR_Q1, LDPC_PRIO_ROWS_PAIR_Q2, LDPC_PRIO_ROWS_PAIR_Q3};
-                    constexpr int prio_rows[6] = {prio_tab[JW][0], prio_tab[JW][1], prio_tab[JW][2], prio_tab[JW][3], prio_tab[JW][4], prio_tab[JW][5]};
+                {   // (per-quarter tables against the age bias of the issue arbitration all measured <= this uniform one)
+                    constexpr int prio_rows[6] = LDPC_PRIO_ROWS_PAIR;
                     constexpr int step = Rw * IPT + S, nsteps = IPT * NROWS;
                     constexpr int k = step - (nsteps - 6);
                     constexpr int now = k >= 0 ? prio_rows[k] : 3, before = (step > 0 && k >= 1) ? prio_rows[k - 1] : 3;
@@ -373,12 +268,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 }
                 R a[D], e[D];
                 int sr[D], xw[D];
-#if LDPC_PAIR_ROWWISE
-                static_for<0, D>([&](auto J_) LDPC_INLINE {                            // (3) this row's exchanged edges
-                    constexpr int B = row_block(P, Rw, decltype(J_)::value);
-                    if constexpr (exch_slot(P, B) >= 0) edge_update(S_, IC<B>{}, xs[S][B]);
-                });
-#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
@@ -389,9 +278,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 });
                 const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
                 exclusive_min<O, D, true, CAP>(a, e);                                  // :391-395, :430-435
-#ifdef LDPC_PAIR_TAIL_PRIO
-                if constexpr (Rw == NROWS - 1 && S == IPT - 1) LDPC_SETPRIO(LDPC_PAIR_TAIL_PRIO);
-#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
@@ -415,11 +301,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     if (blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
         cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-#if !LDPC_PAIR_EARLY_FETCH
-        if (!first) fetch_llrs(cw);
-#else
-        (void)first;
-#endif
+        (void)first;                              // (this codeword's LLR loads were issued behind the previous epilogue)
         begin_codeword();
         bool done = false, ok = false;
         uint32_t iters = maxiters;
@@ -437,12 +319,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
                 else if (it == maxiters) { done = true; }
                 if (done) break;
-#if LDPC_PAIR_SKIP_FIRST
-                if (it == 0) variable_phase(IC<1>{});     // nothing to read yet: the exchange slots are not even zeroed
-                else variable_phase(IC<0>{});
-#else
-                variable_phase(IC<0>{});
-#endif
+                variable_phase();
 #ifdef LDPC_DIAG_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -473,9 +350,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             d[0] += acc_var; d[1] += acc_w2; d[2] += acc_chk; d[3] += acc_w1;
         }
 #endif
-#if LDPC_PAIR_EARLY_FETCH
-        if (g + gridDim.x < n_groups) fetch_llrs((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));   // behind the epilogue
-#endif
+        // the next codeword's LLR loads, issued before this one's epilogue (fixed cost per codeword 2.55 -> 2.12 us)
+        if (g + gridDim.x < n_groups) fetch_llrs((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
         // s_bitreplicate doubles every bit), then bit-reversed per byte
@@ -512,8 +388,7 @@ decode_ms_pair_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output, 
 {
     using GEO = PairGeometry<CODE, T>;
     __shared__ __attribute__((aligned(16))) char lds[GEO::LDS_BYTES];
-    constexpr int qmap[4] = LDPC_PAIR_QMAP;
-    const int jw = qmap[__builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8)];   // quarter of this wave's indices
+    const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8);          // quarter of this wave's indices
     if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
     else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
     else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);

@@ -1,0 +1,84 @@
+// decode_ms_tuning.hpp -- the tuned settings of the min-sum kernels, in one place.
+//
+// A LIBRARY build uses exactly the values below.  They can be overridden -- and the LDPC_DIAG_* timing
+// diagnostics, which produce WRONG decodes, enabled -- only in a translation unit that defines LDPC_KBENCH
+// before including the kernels, which tools/kbench.hip (the same-process A/B timing tool) does and the
+// library's Makefile never does: a stray -DLDPC_... in EXTRA stops the build here instead of shipping a
+// mistuned or broken decoder.
+#pragma once
+
+#ifndef LDPC_KBENCH
+#if defined(LDPC_DIAG_NOBARRIER) || defined(LDPC_DIAG_FIXED_ITERS) || defined(LDPC_DIAG_NOLDS) || defined(LDPC_DIAG_NOSELFCORR) || \
+    defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
+    defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
+    defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR)
+#error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
+#endif
+#endif
+
+// ---- decode_ms_kernel.hpp ---------------------------------------------------------------------------------
+// Quarter-specialised bodies (one copy per starting quarter, every pi_k constant a literal): 2 = for
+// workgroups spanning two or four quarters (+4.6 % on TM8192), 1 = two only, 0 = off.
+#ifndef LDPC_QUARTER_SPECIALISE
+#define LDPC_QUARTER_SPECIALISE 2
+#endif
+// f32: clamp-free check phase for codewords whose LLRs are bounded (NOCAP_POSSIBLE in the kernel body).
+#ifndef LDPC_NOCAP
+#define LDPC_NOCAP 1
+#endif
+// Local-edge updates done at the end of the variable phase: -1 = per kernel (local_in_var_default()).
+#ifndef LDPC_LOCAL_IN_VAR
+#define LDPC_LOCAL_IN_VAR -1
+#endif
+// Progress-based wave priority.  VALU issue is arbitrated by priority, then age, so the oldest wave
+// of a SIMD runs ahead and the youngest arrives last at every barrier, the last stretch of each
+// phase with the SIMD half empty.  Lowering a wave's priority as it advances through a phase
+// lets the laggards catch up.  The schedule that measured best keeps priority 3 through the edge
+// updates and steps down over the last check rows (LDPC_PRIO_ROWS; a sweep of a dozen schedules spans
+// 6.06-6.40 M codewords/s on TM8192, the inverted one 5.54): TM8192 5.61 -> 6.40, TM6144 9.64 ->
+// 10.83, TM2048 46.9 -> 48.1, TM5120 13.76 -> 14.02 M codewords/s.  Only for codewords of 8 or more waves
+// (PRIO_WAVES in the kernel): with one or two waves per codeword it costs (TC512 -7 %, TM1280 -1 %).
+// 0 = off, 1 = with a scheduling barrier at each step, 2 = plain.
+#ifndef LDPC_PRIO
+#define LDPC_PRIO 2
+#endif
+#ifndef LDPC_PRIO_ROWS
+#define LDPC_PRIO_ROWS {2, 2, 1, 1, 1, 0}        // priority during the last six (index, check row) steps of the check phase
+#endif
+#ifndef LDPC_PRIO_ROWS_LEAN
+#define LDPC_PRIO_ROWS_LEAN {3, 3, 3, 2, 1, 0}   // the same for the register-lean check phase
+#endif
+#ifndef LDPC_PRIO_VAR
+#define LDPC_PRIO_VAR 2                          // priority of the first half of the (short) variable phase
+#endif
+// Waves per SIMD the TM2048 kernels' register allocation must leave room for (min_waves_per_simd()).
+#ifndef LDPC_TM2048_WAVES
+#define LDPC_TM2048_WAVES 6
+#endif
+
+// ---- decode_ms_pair.hpp (each measured with tools/kbench.hip -DKPAIR=1 on TM8192) ---------------------------
+// How many of the thread's local-edge updates (of 14 on TM8192) are done at the end of the variable phase
+// (LDS-bound: the VALU idles there) instead of at the start of the check phase (VALU-bound), where the
+// rest still covers the latency of the marginal reads.  f32 0/3/5/7/9/14 -> 7.04 / 7.07 / 7.24 / 7.41 /
+// 7.32 / 7.26 M codewords/s; i8 0/4/7 -> 9.29 / 9.61 / 8.31.  -1 = per type (7 for f32, 4 else).
+#ifndef LDPC_PAIR_LOCAL_IN_VAR
+#define LDPC_PAIR_LOCAL_IN_VAR -1
+#endif
+// f32: run the check phase without the FLT_MAX clamp of the exclusive minimum when no LLR of the codeword
+// exceeds the launch's nocap_limit in magnitude (see begin_codeword): 6.84 -> 7.05.
+#ifndef LDPC_PAIR_NOCAP
+#define LDPC_PAIR_NOCAP 1
+#endif
+// Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = per type (on for
+// i8/i16: 8.0 -> 9.0; off for f32: 7.05 -> 6.90), 0 / 1 = force.
+#ifndef LDPC_PAIR_ODD_B64
+#define LDPC_PAIR_ODD_B64 -1
+#endif
+// Wave priority over the six (check row, index) steps of the check phase; 3 before them.  A dozen
+// alternatives, also per quarter, measured 6.4-6.75 against 6.75 for this one.
+#ifndef LDPC_PRIO_ROWS_PAIR
+#define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}
+#endif
+// Diagnostics (LDPC_KBENCH only, wrong or perturbed results): LDPC_DIAG_NOBARRIER, LDPC_DIAG_NOLDS,
+// LDPC_DIAG_NOMIN, LDPC_DIAG_NOSELFCORR, LDPC_DIAG_FIXED_ITERS, LDPC_DIAG_STAMPS (per-phase s_memtime sums).

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
+#define LDPC_KBENCH 1          // the only place the kernels' experiment switches may be set (decode_ms_tuning.hpp)
 #include "decode_ms_kernel.hpp"
 #include "decode_ms_pair.hpp"
 #include "channel.hpp"
