@@ -158,7 +158,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 
     auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-        const R nv = O::sub(x, u[S][B]);                                               // :421
+        const R nv = O::sub_nv(x, u[S][B]);                                            // :421
         v[S][B] = O::template self_correct<true>(nv, v[S][B]);                         // :422-425
     };
 
