@@ -341,11 +341,22 @@ int host_pipeline(const void *in, size_t in_bytes_per_item, const HostOut (&outs
 // so no size_t batch is ever truncated.
 constexpr size_t MAX_LAUNCH_FRAMES = (size_t)1 << 30;
 
+// (LABRADOR_LDPC_HIP_MAX_LAUNCH=<frames, a multiple of 8> lowers the slice for tests)
+size_t max_launch_frames()
+{
+    if (const char *env = std::getenv("LABRADOR_LDPC_HIP_MAX_LAUNCH")) {
+        const long long v = std::atoll(env);
+        if (v >= 8 && (size_t)v <= MAX_LAUNCH_FRAMES && v % 8 == 0) return (size_t)v;
+    }
+    return MAX_LAUNCH_FRAMES;
+}
+
 template <class Launch>                                        // launch(first_frame, frames) -> hipError_t
 hipError_t for_launch_slices(size_t batch, Launch launch)
 {
-    for (size_t f0 = 0; f0 < batch; f0 += MAX_LAUNCH_FRAMES) {
-        const size_t nb = batch - f0 < MAX_LAUNCH_FRAMES ? batch - f0 : MAX_LAUNCH_FRAMES;
+    const size_t slice = max_launch_frames();
+    for (size_t f0 = 0; f0 < batch; f0 += slice) {
+        const size_t nb = batch - f0 < slice ? batch - f0 : slice;
         if (hipError_t e = launch(f0, nb); e != hipSuccess) return e;
     }
     return hipSuccess;

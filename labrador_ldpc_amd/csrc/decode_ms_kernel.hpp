@@ -214,8 +214,14 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // compare decide it; "-0.0 < 0" is false, which is the old == 0 case.
     LDPC_DEV static bool drop(R nv, R old)
     {
+#ifdef LDPC_DIAG_MULDROP
+        float p;
+        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
+        return p < 0.0f;
+#else
         const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
         return __int_as_float(t) < 0.0f;
+#endif
     }
     // nv, or +0 where drop(nv, old)  (zeroing by EXEC predication instead of v_cndmask measured slower:
     // EXEC writes stall the VALU -- DESIGN.md 4.4)

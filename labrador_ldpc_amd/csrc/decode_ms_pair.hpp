@@ -159,7 +159,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         const R nv = O::sub_nv(x, u[S][B]);                                            // :421
+#ifdef LDPC_DIAG_NOSELFCORR
+        v[S][B] = nv;
+#else
         v[S][B] = O::template self_correct<true>(nv, v[S][B]);                         // :422-425
+#endif
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
@@ -276,12 +280,24 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                     if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
+#ifdef LDPC_DIAG_NOPAR
+                const int sgn = xor_reduce<D>(sr), par = xw[0];
+#else
                 const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
+#endif
+#ifdef LDPC_DIAG_NOMIN
+                static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = a[(decltype(J_)::value + 1) % D]; });
+#else
                 exclusive_min<O, D, true, CAP>(a, e);                                  // :391-395, :430-435
+#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
+#ifdef LDPC_DIAG_NOSIGN
+                    u[S][B] = e[J];
+#else
                     u[S][B] = O::apply_sign(e[J], sgn, sr[J]);                         // :398-405
+#endif
                     constexpr int slot = exch_slot(P, B);
                     if constexpr (slot >= 0) {
                         constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);

@@ -24,6 +24,9 @@ CONFIGS = [
     pytest.param(LDPCCode.TM2048, "f32", 1048576, 2.0, id="config3-TM2048-f32-1048576"),
     pytest.param(LDPCCode.TM8192, "f32", 524288, 2.0, id="config4-TM8192-f32-524288-per-gpu"),
     pytest.param(LDPCCode.TM5120, "i8", 524288, 4.0, id="config5-TM5120-i8-524288-per-gpu"),
+    # SURVEY.md 8(d)'s second operating point of config 5: at 2 dB a rate-4/5 code never converges, so every
+    # frame does the full 25 iterations (fixed work) and returns (false, 25) with the last hard decision
+    pytest.param(LDPCCode.TM5120, "i8", 524288, 2.0, id="config5-TM5120-i8-524288-per-gpu-2dB-fixed-work"),
 ]
 
 
@@ -86,6 +89,9 @@ def test_full_batch_properties(code, dtype, frames, ebn0):
     # idempotence of decode on its own successful outputs
     del llrs
     succ_idx = torch.nonzero(okb).flatten()
+    if code == LDPCCode.TM5120 and ebn0 <= 2.0:
+        assert succ_idx.numel() == 0 and bool((iters == maxiters).all())          # fixed-work regime
+        return
     assert succ_idx.numel() > 0
     clean = _hard_llrs(code, out[succ_idx], dtype)
     o3, i3, k3 = code.decode_ms_batch(clean, maxiters)

@@ -164,3 +164,27 @@ def test_device_calls_can_be_captured_in_a_hip_graph():
         torch.cuda.synchronize()
         assert (llrs.cpu().numpy() == ref_llrs).all()
         assert (out.cpu().numpy() == ref[0]).all() and (it.cpu().numpy() == ref[1]).all() and (ok.cpu().numpy() == ref[2]).all()
+
+
+def test_device_batches_larger_than_one_launch_are_sliced(monkeypatch):
+    """The kernels take 32-bit frame counts; a device-resident batch is enqueued as launches of at most 2^30
+    frames (no size_t batch may be truncated).  The slice is lowered here so that a small batch
+    exercises the slicing arithmetic (pointer offsets of all four buffers, ragged last slice, TC128 packs four
+    codewords per wave) for decode_ms, decode_bf and the encoder."""
+    monkeypatch.setenv("LABRADOR_LDPC_HIP_MAX_LAUNCH", "1000")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4)
+    for code, frames in ((LDPCCode.TC128, 3503), (LDPCCode.TM1280, 2077)):
+        llrs, _ = oracle.awgn_llrs(code, rng, frames, 4.0, np.float32)
+        out, it, ok = code.decode_ms_batch(torch.from_numpy(llrs).to(dev), 20)
+        ref = oracle.decode_ms_batch(code, llrs, 20)
+        assert (out.cpu().numpy() == ref[0]).all() and (it.cpu().numpy() == ref[1]).all() and (ok.cpu().numpy() == ref[2]).all()
+        data = rng.integers(0, 256, size=(frames, code.k() // 8), dtype=np.uint8)
+        cws = code.encode_batch(torch.from_numpy(data).to(dev))
+        monkeypatch.delenv("LABRADOR_LDPC_HIP_MAX_LAUNCH")
+        assert torch.equal(cws, code.encode_batch(torch.from_numpy(data).to(dev)))
+        monkeypatch.setenv("LABRADOR_LDPC_HIP_MAX_LAUNCH", "1000")
+        rx = cws.clone()
+        rx[:, 1] ^= 0x08
+        o_b, i_b, k_b = code.decode_bf_batch(rx, 30)
+        assert bool((k_b == 1).all()) and torch.equal(o_b[:, : code.n() // 8], cws)
