@@ -114,6 +114,28 @@ def test_reference_example_compiles_and_links_unchanged(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+BATCH_SRC = os.path.join(ROOT, "tests", "c", "batch_smoke.c")
+
+
+def test_batched_c_client_compiles_and_reports_no_device(tmp_path):
+    """The batched half of the header from C: compiles with -Wall -Werror, links, and without a GPU exits 77."""
+    exe = build_client(tmp_path, "TM2048", src=BATCH_SRC)
+    if la.device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames", [1, 3001, 40000])
+def test_batched_c_client_on_gpu(tmp_path, frames):
+    """encode_batch -> decode_ms_batch_i8 on one device, on DEVICE_ALL and on a device list, from C, host buffers."""
+    exe = build_client(tmp_path, "TM2048", src=BATCH_SRC)
+    r = subprocess.run([exe, str(frames)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_c_client_end_to_end_on_gpu(tmp_path, name):
