@@ -1,0 +1,52 @@
+"""Condense gpurun_out/<round> (tools/prof_round.sh) into profiles/<round> and refresh profiles/hbm_traffic.json:
+kernel-trace stats of every decode kernel of the default bench command, per-launch means of every PMC counter per
+configuration, HBM traffic corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950) + WRITE_SIZE.
+    python tools/summarise_round.py r02_final"""
+import csv, glob, json, os, shutil, sys
+name = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+src, dst = f"gpurun_out/{name}", f"profiles/{name}"
+os.makedirs(dst, exist_ok=True)
+for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+    rows = list(csv.reader(open(f)))
+    keep = [rows[0]] + [r for r in rows[1:] if "ldpc::" in r[0]]
+    csv.writer(open(f"{dst}/kernel_stats_bench_default.csv", "w", newline="")).writerows(keep)
+for f in ("bench_default.json", "trace_bench.log"):
+    if os.path.exists(f"{src}/{f}"):
+        shutil.copy(f"{src}/{f}", f"{dst}/{'bench_under_rocprof.log' if f == 'trace_bench.log' else f}")
+CONFIGS = {"TM8192_f32": (65536, 8192 * 4 + 1280 + 5), "TC512_f32": (65536, 512 * 4 + 64 + 5),
+           "TM2048_f32": (262144, 2048 * 4 + 320 + 5), "TM5120_i8": (131072, 5120 + 704 + 5)}
+traffic, allsum = {}, {}
+for tag, (frames, alg) in CONFIGS.items():
+    summary = {}
+    for i in range(1, 6):
+        for f in glob.glob(f"{src}/{tag}.pmc{i}/*/*_counter_collection.csv"):
+            if tag == "TM8192_f32":
+                shutil.copy(f, f"{dst}/pmc{i}_counters_{tag}.csv")
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if "decode_ms_" not in r["Kernel_Name"]:
+                    continue
+                acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for cname, per in acc.items():
+                summary[cname] = sum(per.values()) / len(per)          # mean per launch
+    if not summary:
+        continue
+    allsum[tag] = dict(summary, frames_per_launch=frames)
+    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        hbm = (2.0 * summary["FETCH_SIZE"] + summary["WRITE_SIZE"]) * 1024.0      # KB -> B; FETCH_SIZE doubled: gfx950 correction
+        traffic[tag] = {"frames": frames, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": frames * alg,
+                        "hbm_over_algorithmic": hbm / (frames * alg),
+                        "fetch_size_kb_raw": summary["FETCH_SIZE"], "write_size_kb_raw": summary["WRITE_SIZE"],
+                        "valu_insts_per_launch": summary.get("SQ_INSTS_VALU"), "lds_insts_per_launch": summary.get("SQ_INSTS_LDS"),
+                        "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/prof_round.sh, {dst}); "
+                                "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md"}
+json.dump(allsum, open(f"{dst}/pmc_summary.json", "w"), indent=1)
+if traffic:
+    json.dump(traffic, open("profiles/hbm_traffic.json", "w"), indent=1)
+for tag, s in allsum.items():
+    w = s.get("SQ_WAVE_CYCLES")
+    if w:
+        print(tag, {k: round(s[k] / w, 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS") if k in s},
+              "LDS conflict share", round(s.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, s.get("SQ_LDS_IDX_ACTIVE", 1)), 3),
+              "HBM/alg", round(traffic[tag]["hbm_over_algorithmic"], 4) if tag in traffic else None)
