@@ -313,6 +313,12 @@ int labrador_ldpc_hip_awgn_i8 (enum labrador_ldpc_code code, const uint8_t *code
  * generated from against the reference's nine known answers without a GPU. */
 uint32_t labrador_ldpc_hip_edge_crc(enum labrador_ldpc_code code);
 
+/* The parity-check edges (check, variable) of this library's code tables in the order of the reference's
+ * LDPCCode::iter_paritychecks() (src/codes/mod.rs:435-441, body :275-362; variables n .. n+p-1 are the
+ * punctured ones).  Writes up to `cap` pairs (either array may be NULL) and returns the number of edges
+ * (= paritycheck_sum, src/codes/mod.rs:405-409); 0 for a bad code. */
+size_t labrador_ldpc_hip_edges(enum labrador_ldpc_code code, uint16_t *checks, uint16_t *variables, size_t cap);
+
 /* The contiguous slice [*first, *first + *count) of `batch` frames that part `index` of `parts`
  * takes in a sharded call (slices differ by at most one frame).  Returns a status code. */
 int labrador_ldpc_hip_shard_range(size_t batch, size_t parts, size_t index, size_t *first, size_t *count);

@@ -79,6 +79,7 @@ SYMBOLS = {
     "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
                                          _c.c_uint64, _optp]),
     "labrador_ldpc_hip_edge_crc": (_c.c_uint32, [_int]),
+    "labrador_ldpc_hip_edges": (_sz, [_int, _vp, _vp, _sz]),
     "labrador_ldpc_hip_shard_range": (_int, [_sz, _sz, _sz, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "labrador_ldpc_hip_device_count": (_int, []),
     "labrador_ldpc_hip_last_error": (_c.c_char_p, []),
@@ -238,6 +239,15 @@ class LDPCCode(enum.IntEnum):
 
     def paritycheck_sum(self) -> int:
         return (self.decode_ms_working_len() - 3 * self.n() - 3 * self.punctured_bits() + 2 * self.k()) // 2
+
+    def iter_paritychecks(self):
+        """(check, variable) index arrays of every parity-check edge in the crate's iteration order
+        (src/codes/mod.rs:435-441), from the tables the kernels are generated from."""
+        E = self.paritycheck_sum()
+        chk, var = np.empty(E, dtype=np.uint16), np.empty(E, dtype=np.uint16)
+        got = lib.labrador_ldpc_hip_edges(int(self), chk.ctypes.data, var.ctypes.data, E)
+        assert got == E
+        return chk, var
 
     # ---- sizes: src/decoder.rs:93-116 ----
     def decode_bf_working_len(self) -> int:

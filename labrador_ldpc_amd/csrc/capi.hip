@@ -795,6 +795,21 @@ int labrador_ldpc_hip_awgn_i8(enum labrador_ldpc_code c, const uint8_t *codeword
 // ---- introspection ---------------------------------------------------------------------------------
 uint32_t labrador_ldpc_hip_edge_crc(enum labrador_ldpc_code c) { return ldpc::valid_code(c) ? ldpc::edge_crc(c) : 0; }
 
+// iter_paritychecks() (src/codes/mod.rs:435-441) as a list: the edges in the reference's order
+size_t labrador_ldpc_hip_edges(enum labrador_ldpc_code c, uint16_t *checks, uint16_t *variables, size_t cap)
+{
+    if (!ldpc::valid_code(c)) return 0;
+    size_t e = 0;
+    ldpc::for_each_edge(c, [&](int chk, int var) {
+        if (e < cap) {
+            if (checks) checks[e] = (uint16_t)chk;
+            if (variables) variables[e] = (uint16_t)var;
+        }
+        ++e;
+    });
+    return e;
+}
+
 int labrador_ldpc_hip_device_count(void)
 {
     int count = 0;

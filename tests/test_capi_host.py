@@ -48,6 +48,27 @@ def test_tables_reproduce_reference_kats(code, kats):
     assert (cw2 == cw).all()
 
 
+@pytest.mark.parametrize("code", list(LDPCCode), ids=NAMES)
+def test_iter_paritychecks_list(code, kats):
+    """The product's own edge list: count == paritycheck_sum (src/codes/mod.rs:532), CRC of the listed pairs ==
+    the reference's known answer (:521-523), and identical to the oracle's independently written enumerator."""
+    import oracle
+    chk, var = code.iter_paritychecks()
+    assert len(chk) == code.paritycheck_sum() == kats["sizes"][code.name]["paritycheck_sum"]
+    crc = 0xFFFFFFFF
+    for c, v in zip(chk.tolist(), var.tolist()):
+        for word in (c, v):
+            crc ^= word
+            for _ in range(16):
+                crc = (crc >> 1) ^ (0xEDB88320 if crc & 1 else 0)
+    assert crc == kats["edge_crc"][int(code)]
+    o_chk, o_var = oracle.edges(code)
+    assert (chk == o_chk).all() and (var == o_var).all()
+    assert int(var.max()) == code.n() + code.punctured_bits() - 1 and int(chk.max()) == code.n() + code.punctured_bits() - code.k() - 1
+    assert la.lib.labrador_ldpc_hip_edges(int(code), None, None, 0) == len(chk)        # count-only call
+    assert la.lib.labrador_ldpc_hip_edges(99, None, None, 0) == 0
+
+
 def test_encoder_matches_oracle_on_random_data():
     import oracle
     rng = np.random.default_rng(1)
