@@ -139,3 +139,34 @@ def test_bad_ordinal_in_device_list_is_reported():
     with pytest.raises(la.LdpcHipError) as e:
         code.decode_ms_batch(llrs, 5, devices=[0, 99])
     assert "out of range" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_concurrent_sharded_calls_from_several_host_threads():
+    """The library's device workers are shared by every caller: concurrent sharded calls queue on them and must
+    not mix their slices, statuses or error strings (include/labrador_ldpc_hip.h: 'functions are re-entrant')."""
+    import threading
+    import oracle
+    code = LDPCCode.TM1536
+    rng = np.random.default_rng(31)
+    jobs = []
+    for i in range(6):
+        llrs, _ = oracle.awgn_llrs(code, rng, 500 + 37 * i, 2.5, np.float32 if i % 2 else np.int8)
+        jobs.append((llrs, oracle.decode_ms_batch(code, llrs, 20)[:3], [[0, 0], "all", [0, 0, 0]][i % 3]))
+    results, errors = [None] * len(jobs), []
+
+    def run(i):
+        try:
+            for _ in range(3):
+                results[i] = code.decode_ms_batch(jobs[i][0], 20, devices=jobs[i][2])
+        except Exception as e:           # noqa: BLE001
+            errors.append((i, e))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    for (llrs, want, devs), got in zip(jobs, results):
+        assert all((g == w).all() for g, w in zip(got, want)), devs
