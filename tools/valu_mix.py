@@ -1,0 +1,51 @@
+"""Instruction mix of the TM8192 f32 pair kernel's iteration loop, from the library's own code object, and the
+cycle-weighted VALU issue cost it implies (tools/ubench/valu_rate.hip gives the per-class issue cost at four waves
+per SIMD: 2 cycles for plain VOP1/VOP2 ALU operations, 4 for min/max/compare and the VOP3-only forms, ~3 for
+v_bitop3_b32).  Writes profiles/<round>/valu_mix_tm8192_f32.json.
+    python tools/valu_mix.py r02_final"""
+import collections, json, os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+name = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tmp = tempfile.mkdtemp()
+subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", os.path.join(ROOT, "build/csrc/decode_ms_f32.o"), "/dev/null"])
+subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat", f"--output={tmp}/co", "--unbundle"])
+dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", f"{tmp}/co"], text=True).split("\n")
+cur, body = None, []
+for l in dis:
+    m = re.match(r"^[0-9a-f]+ <(\S+)>:", l)
+    if m:
+        cur = m.group(1)
+        continue
+    if cur and "decode_ms_pair_kernelILi8Ef" in cur:
+        body.append(l.split("//")[0].strip())
+# the iteration loop of the first quarter body: the two longest barrier-to-barrier segments that repeat
+bars = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
+segs = sorted(((b - a, a, b) for a, b in zip(bars, bars[1:])), reverse=True)
+check = next(s for s in segs)                          # longest = a check phase
+var = next(s for s in segs if s[2] == check[1])        # the segment ending where it starts = the variable phase
+loop = body[var[1]:check[2]]
+FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|fma|pk_|lshl_add|lshl_or|xad)")
+cls = collections.Counter()
+ops = collections.Counter()
+for l in loop:
+    if not l.startswith("v_"):
+        continue
+    op = l.split()[0]
+    ops[op] += 1
+    if op.startswith("v_bitop3"):
+        cls["bitop3 (3 cycles)"] += 1
+    elif FOUR.match(op):
+        cls["4-cycle (min/max/med3/compare/VOP3-only)"] += 1
+    else:
+        cls["2-cycle (plain VOP1/VOP2)"] += 1
+n = sum(cls.values())
+avg = (2 * cls["2-cycle (plain VOP1/VOP2)"] + 3 * cls["bitop3 (3 cycles)"] + 4 * cls["4-cycle (min/max/med3/compare/VOP3-only)"]) / n
+out = {"kernel": "decode_ms_pair_kernel<8, float>, quarter-0 body, one iteration (variable + check phase)",
+       "valu_instructions_per_wave_iteration": n, "classes": dict(cls), "avg_issue_cycles_per_instruction": avg,
+       "other": {"ds": sum(1 for l in loop if l.startswith("ds_")), "salu": sum(1 for l in loop if l.startswith("s_"))},
+       "top_opcodes": ops.most_common(14),
+       "note": "static count over both clamp modes' code is avoided by taking ONE loop copy; issue costs per class from tools/ubench (valu_rate / valu_pairs, 4 waves per SIMD)"}
+os.makedirs(os.path.join(ROOT, "profiles", name), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", name, "valu_mix_tm8192_f32.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
