@@ -6,10 +6,10 @@ from labrador_ldpc_amd import LDPCCode
 t0 = time.time(); total = 0; bad_total = 0
 for code in LDPCCode:
     frames = 1500 if code.n() <= 2048 else 400
-    for dtype in (np.float32, np.int8, np.int16, np.float64):
+    for dtype in (np.float32, np.int8, np.int16, np.int32, np.float64):
         rng = np.random.default_rng(4242 + 17 * int(code) + np.dtype(dtype).itemsize)
         for ebn0, mi in ((0.5, 8), (1.5, 30), (2.5, 25), (4.0, 25), (7.0, 10)):
-            scale, lim = (8.0, 31) if dtype == np.int8 else (64.0, 4095)
+            scale, lim = (8.0, 31) if dtype == np.int8 else ((3e8, 2 ** 31 - 1) if dtype == np.int32 else (64.0, 4095))
             llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, dtype, scale=scale, lim=lim)
             o, it, ok = code.decode_ms_batch(llrs, mi)
             oc, itc, okc, _ = oracle.decode_ms_batch(code, llrs, mi)

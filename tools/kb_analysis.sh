@@ -6,11 +6,11 @@ HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-fast-math -
 kb() {   # label, flags...
   label=$1; shift
   $HIPCC -DKPAIR=1 -DKGRID=256 "$@" -o /tmp/kb_$$ tools/kbench.hip labrador_ldpc_amd/csrc/channel.hip 2>&1 | grep -E "error" -A3
-  printf "%-58s " "$label"; /tmp/kb_$$ | tail -1
+  printf "%-58s " "$label"; /tmp/kb_$$ | tail -${KB_TAIL:-1}
 }
 echo "== shipped kernel, early termination (2 dB, 65536 frames, persistent grid of 256 workgroups) =="
 kb "shipped" -DKFRAMES=65536
-kb "phase stamps (s_memtime; perturbs the timing)" -DKFRAMES=65536 -DLDPC_DIAG_STAMPS | tail -7
+KB_TAIL=6 kb "phase stamps (s_memtime; perturbs the timing)" -DKFRAMES=65536 -DLDPC_DIAG_STAMPS
 kb "odd rotations as aligned 64-bit reads (LDPC_PAIR_ODD_B64=1)" -DKFRAMES=65536 -DLDPC_PAIR_ODD_B64=1
 kb "sign test of the self-correction as v_mul_f32 (MULDROP)" -DKFRAMES=65536 -DLDPC_DIAG_MULDROP
 echo "== leave-one-out, 25 iterations for every frame (results wrong by construction) =="
