@@ -178,8 +178,13 @@ def run_rank(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the decoder has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank: local rank r uses device r, unless --devices maps ranks to ordinals explicitly (testing
+    # the N > 1 path on a box with fewer GPUs: "--gpus 2 --devices 0,0")
+    ordinal = int(args.devices.split(",")[local_rank]) if args.devices else local_rank
+    if ordinal >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: device {ordinal} requested, {torch.cuda.device_count()} visible")
+    torch.cuda.set_device(ordinal)
+    dev = torch.device("cuda", ordinal)
 
     code = LDPCCode[args.code]
     F = args.frames_per_gpu
@@ -279,6 +284,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=524288)
     ap.add_argument("--pool", type=int, default=256, help="distinct random codewords the frames cycle through")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--devices", default="", help="comma-separated device ordinal per local rank (default: rank r -> device r)")
     ap.add_argument("--cpu-frames", type=int, default=16384,
                     help="all-core cpu_baseline sample in TM8192-sized frames (one core: 1/16 of it)")
     ap.add_argument("--config-steps", type=int, default=5, help="timed launches per extra BASELINE config")
