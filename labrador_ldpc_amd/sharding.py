@@ -79,7 +79,17 @@ def init_ranks() -> Tuple[int, int, int]:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo announces its connections on STDOUT from C++; the caller's stdout carries exactly one JSON
+            # line (bench.py), so the file descriptor is pointed at stderr for the duration of the rendezvous
+            sys.stdout.flush()
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()                    # the peers' connection messages appear here
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
     return rank, local_rank, world
 
 
