@@ -12,7 +12,7 @@ def rate(fn, n):
     for _ in range(3):
         t = time.perf_counter(); fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
     return n / best / 1e6
-print("code    Eb/N0  frames   mean_it   f32 M/s   i8 M/s  i16 M/s  f64 M/s  encode M/s  decode_bf M/s")
+print("code    Eb/N0  frames   mean_it   f32 M/s   i8 M/s  i16 M/s  i32 M/s  f64 M/s  encode M/s  decode_bf M/s")
 for code in LDPCCode:
     eb = EBN0[code.name]
     frames = max(16384, min(1048576, (1 << 31) // (code.n() * 8)))
@@ -26,6 +26,9 @@ for code in LDPCCode:
     r32 = rate(lambda: code.decode_ms_batch(f32, 25), frames)
     r8 = rate(lambda: code.decode_ms_batch(i8, 25), frames)
     r16 = rate(lambda: code.decode_ms_batch(i16, 25), frames)
+    i32 = (f32.double() * 1e6).round().clamp(-2e9, 2e9).to(torch.int32)
+    ri32 = rate(lambda: code.decode_ms_batch(i32, 25), frames)
+    del i32
     f64frames = frames if code.name != "TM8192" else 16384
     f64 = f32[:f64frames].double()
     r64 = rate(lambda: code.decode_ms_batch(f64, 25), f64frames)
@@ -36,4 +39,4 @@ for code in LDPCCode:
     idx = torch.randint(0, code.n() // 8, (frames,), device=dev)
     hard[torch.arange(frames, device=dev), idx] ^= 0x10
     rbf = rate(lambda: code.decode_bf_batch(hard, 50), frames)
-    print(f"{code.name:7s} {eb:4.1f} {frames:8d} {float(it.float().mean()):8.2f} {r32:9.2f} {r8:8.2f} {r16:8.2f} {r64:8.3f} {renc:10.1f} {rbf:10.1f}", flush=True)
+    print(f"{code.name:7s} {eb:4.1f} {frames:8d} {float(it.float().mean()):8.2f} {r32:9.2f} {r8:8.2f} {r16:8.2f} {ri32:8.2f} {r64:8.3f} {renc:10.1f} {rbf:10.1f}", flush=True)
