@@ -35,3 +35,30 @@ def test_cli_prints_reference_csv_columns(capsys):
     line = capsys.readouterr().out.strip().splitlines()[-1].split(",")
     assert line[0] == "TC128" and line[1] == "2.00" and len(line) == 6
     assert int(line[3]) == int(line[2]) * 64 and float(line[5]) > 0
+
+
+def test_native_perftest_binary_matches_the_python_harness():
+    """harness/perftest.cpp -- the reference's perftest (perftest/src/main.rs) as a native program over the C ABI,
+    one worker thread per GPU: CSV columns and stopping rule of the reference, BER statistically equal to the
+    Python harness's at the same operating points, monotone in the SNR, and with a device list."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "harness"), "-s"])
+    exe = os.path.join(root, "build", "perftest")
+    r = subprocess.run([exe, "TM1280", "--noise", "ebn0", "--snrs", "2.0,3.0,3.6,5.0", "--max-bits", "6e7", "--batch", "16384",
+                        "--maxiters", "50", "--devices", "0,0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split(",") for ln in r.stdout.strip().splitlines()]
+    assert [row[0] for row in rows] == ["TM1280"] * 4 and [row[1] for row in rows] == ["2.00", "3.00", "3.60", "5.00"]
+    code = LDPCCode.TM1280
+    bers = []
+    for name, snr, trials, bits, errors, ber in rows:
+        assert int(bits) == int(trials) * code.k() and int(errors) >= 1
+        assert abs(float(ber) - int(errors) / int(bits)) <= 1e-4 * float(ber)
+        assert int(bits) > 6e7 or int(errors) > 5000                              # the reference's stopping rule (:50)
+        bers.append(float(ber))
+    assert bers[0] > bers[1] > bers[2] > bers[3]
+    for snr, ber in ((2.0, bers[0]), (3.0, bers[1])):                              # points with thousands of errors
+        _, _, errors, ber_py, _ = perftest.ms_trials(code, snr, "ebn0", maxiters=50, batch=16384, max_bits=6e7)
+        assert errors > 1000 and 0.8 < ber / ber_py < 1.25, (snr, ber, ber_py)
