@@ -86,6 +86,70 @@ encode_kernel(const uint32_t *__restrict__ gt,     // [n-k][KW] generator column
     }
 }
 
+// k = 4096 (TM5120, TM6144, TM8192): the frame data reaches the arithmetic through LDS instead of the scalar
+// cache.  A scalar load's latency (~400 cycles) cannot be hidden behind more than one chunk of arithmetic -- SMEM
+// returns out of order, so a wave can only wait for ALL its outstanding loads -- which left the kernel above at a
+// third of the VALU's rate for these codes.  Here the workgroup stages eight consecutive frames (4 KB, one 16-byte
+// global load per thread, double-buffered, the next group's loads in flight during the arithmetic) and every wave
+// reads a frame's words back as 32 broadcast ds_read_b128 (in-order, deeply pipelined by the hardware).
+__global__ void __launch_bounds__(256, 2)
+encode_kernel_k4096(const uint32_t *__restrict__ gt, const uint8_t *__restrict__ data, uint8_t *__restrict__ codewords,
+                    uint32_t batch, uint32_t n_bytes, uint32_t n_parity, uint32_t frames_per_wg)
+{
+    constexpr int KW = 128, KB = 512, FB = 8;
+    __shared__ uint4 stage[2][FB * KB / 16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t p = blockIdx.x * 256 + tid;                  // parity column
+    const bool active = p < n_parity;
+    uint32_t g[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) g[w] = active ? gt[(size_t)p * KW + w] : 0u;
+
+    const uint32_t f_begin = blockIdx.y * frames_per_wg;
+    if (f_begin >= batch) return;                               // (uniform over the workgroup)
+    const uint32_t f_end = f_begin + frames_per_wg < batch ? f_begin + frames_per_wg : batch;
+    auto load_group = [&](uint32_t fg) -> uint4 {               // this thread's 16 bytes of the 8 frames from fg on
+        if (fg + tid / 32 >= batch) return uint4{0u, 0u, 0u, 0u};
+        return *reinterpret_cast<const uint4 *>(data + (size_t)fg * KB + tid * 16);
+    };
+    uint4 r = load_group(f_begin);
+    int buf = 0;
+    stage[0][tid] = r;
+    __syncthreads();
+    for (uint32_t fg = f_begin; fg < f_end; fg += FB) {
+        const bool more = fg + FB < f_end;
+        if (more) r = load_group(fg + FB);
+        const uint32_t nf = f_end - fg < (uint32_t)FB ? f_end - fg : (uint32_t)FB;
+        for (uint32_t j = 0; j < nf; ++j) {
+            const uint4 *fr = &stage[buf][j * (KB / 16)];
+            uint32_t a4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int w4 = 0; w4 < KW / 4; ++w4) {
+                const uint4 dv = fr[w4];                                                  // same address in every lane
+                a4[0] = __builtin_amdgcn_bitop3_b32(a4[0], g[4 * w4 + 0], dv.x, 0x78);  // acc ^ (g & d)
+                a4[1] = __builtin_amdgcn_bitop3_b32(a4[1], g[4 * w4 + 1], dv.y, 0x78);
+                a4[2] = __builtin_amdgcn_bitop3_b32(a4[2], g[4 * w4 + 2], dv.z, 0x78);
+                a4[3] = __builtin_amdgcn_bitop3_b32(a4[3], g[4 * w4 + 3], dv.w, 0x78);
+            }
+            const uint32_t acc = a4[0] ^ a4[1] ^ a4[2] ^ a4[3];
+            const unsigned long long m = __ballot(__builtin_popcount(acc) & 1);          // bit l = column p0 + l
+            if ((tid & 63) == 0 && active) {                                              // n_parity is a multiple of 64 here
+                const unsigned lo = __builtin_bswap32(__builtin_bitreverse32((unsigned)m));
+                const unsigned hi = __builtin_bswap32(__builtin_bitreverse32((unsigned)(m >> 32)));
+                uint32_t *dst = reinterpret_cast<uint32_t *>(codewords + (size_t)(fg + j) * n_bytes + KB + p / 8);
+                dst[0] = lo;
+                dst[1] = hi;
+            }
+        }
+        // systematic part: the first column group copies the staged data bytes
+        if (blockIdx.x == 0 && fg + tid / 32 < f_end)
+            *reinterpret_cast<uint4 *>(codewords + (size_t)(fg + tid / 32) * n_bytes + (tid % 32) * 16) = stage[buf][tid];
+        if (more) stage[buf ^ 1][tid] = r;
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 struct DeviceGenerator {
     uint32_t *gt = nullptr;
 };
@@ -158,6 +222,17 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
     if (gy > batch) gy = (unsigned)batch;
     if (gy < 1) gy = 1;
     const dim3 grid(gx, gy);
+    if (ci.k == 4096 && (uintptr_t)data % 16 == 0 && (uintptr_t)codewords % 16 == 0 && np % 256 == 0) {
+        // LDS-staged kernel: contiguous runs of frames per workgroup, a multiple of its 8-frame stage
+        int per_cu2 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void *)encode_kernel_k4096, 256, 0) != hipSuccess || per_cu2 < 1) per_cu2 = 2;
+        unsigned gy2 = (unsigned)(cus * per_cu2) / gx > 0 ? (unsigned)(cus * per_cu2) / gx : 1;
+        size_t per_wg = (batch + gy2 - 1) / gy2;
+        per_wg = (per_wg + 7) / 8 * 8;
+        gy2 = (unsigned)((batch + per_wg - 1) / per_wg);
+        hipLaunchKernelGGL(encode_kernel_k4096, dim3(gx, gy2), dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, (uint32_t)per_wg);
+        return hipGetLastError();
+    }
     switch (ci.k / 32) {
         case 2:   hipLaunchKernelGGL((encode_kernel<2>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
         case 4:   hipLaunchKernelGGL((encode_kernel<4>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
