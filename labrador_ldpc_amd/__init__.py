@@ -296,6 +296,8 @@ class LDPCCode(enum.IntEnum):
         Length checks mirror the asserts of src/decoder.rs:356-359; `working`/`working_u8`
         are optional here (the GPU keeps all message state on chip) but are length-checked
         when given."""
+        if not isinstance(llrs, np.ndarray) or llrs.dtype not in _NP_SUFFIX:
+            raise ValueError("llrs must be a numpy array of dtype int8, int16, int32, float32 or float64")
         if llrs.shape != (self.n(),):
             raise ValueError("llrs.len() != n")
         out = _as_u8(output, self.output_len(), "output.len() != (n+p)/8")

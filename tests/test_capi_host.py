@@ -113,6 +113,9 @@ def test_length_checks_mirror_the_crate_asserts():
                        working=np.zeros(3, dtype=np.float32))
     with pytest.raises(ValueError):
         code.encode(np.zeros(code.n() // 8 + 1, dtype=np.uint8))
+    for bad in ([0.0] * code.n(), np.zeros(code.n(), dtype=np.uint16), "llrs"):
+        with pytest.raises(ValueError):
+            code.decode_ms(bad, np.zeros(code.output_len(), dtype=np.uint8))
 
 
 def test_decode_without_gpu_fails_loudly():
