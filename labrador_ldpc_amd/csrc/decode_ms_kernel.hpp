@@ -289,6 +289,19 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
     // work; a - b is exact in f32 (|a - b| < 2^17).  One v_med3 less per edge and iteration.
     LDPC_DEV static R sub_nv(R a, R b) { return a - b; }
     LDPC_DEV static R mag(R x) { return __builtin_fminf(__builtin_fabsf(x), (float)HI); }   // saturating_abs
+    // Self-correction test of decoder.rs:422 for integer-valued messages: old != 0 and the signs differ exactly
+    // when the product is negative -- |nv|, |old| < 2^17, so the f32 product can neither underflow to zero nor
+    // lose its sign (it may round), and nv == 0 gives v = 0 whichever way the test goes.  An F-class v_mul_f32
+    // (co-issues with the 4-cycle instructions of other waves) instead of the VOP3 bit operation of the f32 path,
+    // where the same trick would need a vote on the LLR range (+1 %).
+    LDPC_DEV static bool drop(R nv, R old)
+    {
+        float p;
+        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
+        return p < 0.0f;
+    }
+    template <bool FULL_EXEC>
+    LDPC_DEV static R self_correct(R nv, R old) { return Ops<float>::select_zero(drop(nv, old), nv); }
     template <bool AX>
     LDPC_DEV static R min2_cap(R x)
     {
