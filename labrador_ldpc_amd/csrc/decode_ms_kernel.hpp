@@ -214,19 +214,30 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // compare decide it; "-0.0 < 0" is false, which is the old == 0 case.
     LDPC_DEV static bool drop(R nv, R old)
     {
-#ifdef LDPC_DIAG_MULDROP
-        float p;
-        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
-        return p < 0.0f;
-#else
         const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
         return __int_as_float(t) < 0.0f;
-#endif
     }
     // nv, or +0 where drop(nv, old)  (zeroing by EXEC predication instead of v_cndmask measured slower:
     // EXEC writes stall the VALU -- DESIGN.md 4.4)
     template <bool FULL_EXEC>
     LDPC_DEV static R self_correct(R nv, R old) { return select_zero(drop(nv, old), nv); }
+    // The same for codewords whose LLRs passed the range vote (BOUNDED: every |LLR| <= nocap_limit and every
+    // nonzero |LLR| >= 2^-20, see begin_codeword): "old != 0 and the signs differ" is then exactly "nv * old < 0".
+    // No value is infinite (the nocap bound), and every value of the decode is a multiple of g = 2^(e_min - 23),
+    // e_min >= -20 the exponent of the smallest nonzero |LLR| (sums and differences of multiples of g round to
+    // multiples of g), so a nonzero value is at least 2^-43 and a product of two cannot underflow; nv == 0 gives
+    // v = 0 whichever way the test goes.  An F-class v_mul_f32 in place of the VOP3 bit operation: +1 %.
+    template <bool BOUNDED>
+    LDPC_DEV static R self_correct_b(R nv, R old)
+    {
+        if constexpr (BOUNDED) {
+            float p;
+            asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
+            return select_zero(p < 0.0f, nv);
+        } else {
+            return select_zero(drop(nv, old), nv);
+        }
+    }
     // m >= 0 has bit 31 clear, so "m with sign s_all ^ s_own" is one three-input XOR of sign words
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
@@ -266,6 +277,7 @@ template <> struct Ops<double> {
     {
         return (old != 0.0 && (nv < 0.0) != (old < 0.0)) ? 0.0 : nv;
     }
+    template <bool BOUNDED> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<true>(nv, old); }
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
         return __hiloint2double(__double2hiint(m) ^ s_all ^ s_own, __double2loint(m));
@@ -302,6 +314,7 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
     }
     template <bool FULL_EXEC>
     LDPC_DEV static R self_correct(R nv, R old) { return Ops<float>::select_zero(drop(nv, old), nv); }
+    template <bool BOUNDED> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<true>(nv, old); }
     template <bool AX>
     LDPC_DEV static R min2_cap(R x)
     {
@@ -358,6 +371,7 @@ template <> struct Ops<int32_t> {
     {
         return (old != 0 && ((nv ^ old) < 0)) ? 0 : nv;
     }
+    template <bool BOUNDED> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<true>(nv, old); }
     // m >= 0 negated when the product of the other edges' signs is negative (:398-405)
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
@@ -690,7 +704,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             bool big = false;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 static_for<0, NTX>([&](auto C_) LDPC_INLINE {
-                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= nocap_limit);   // NaN counts as big
+                    const R a = O::mag(llr[decltype(S_)::value][decltype(C_)::value]);
+                    big |= !(a <= nocap_limit) || (a != 0.0f && a < 0x1p-20f);     // NaN counts as out of range
                 });
             });
             if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
@@ -699,14 +714,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
-    auto edge_update = [&](auto S_, auto B_, R x, R uu) LDPC_INLINE {
+    auto edge_update = [&](auto S_, auto B_, R x, R uu, auto BND_) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+        constexpr bool BND = decltype(BND_)::value != 0 && G == 1;
         const R nv = O::sub_nv(x, uu);                                                 // :421
         // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
 #ifdef LDPC_DIAG_NOSELFCORR
         const R nw = nv;
 #else
-        const R nw = O::template self_correct<G == 1>(nv, v[S][B]);
+        const R nw = BND ? O::template self_correct_b<true>(nv, v[S][B]) : O::template self_correct<G == 1>(nv, v[S][B]);
 #endif
         v[S][B] = nw;
     };
@@ -715,16 +731,16 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // the VALU idles there -- the rest at the start of the check phase, where they cover the latency of the
     // marginal reads (TM8192 pair kernel: +5 %; per-code values measured with tools/kbench.hip).
     constexpr int LOCAL_IN_VAR = LDPC_LOCAL_IN_VAR >= 0 ? LDPC_LOCAL_IN_VAR : local_in_var_default<CODE, T, IPT, LEAN>();
-    auto local_edges = [&](auto EARLY_) LDPC_INLINE {
+    auto local_edges = [&](auto EARLY_, auto BND_) LDPC_INLINE {
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
                 if constexpr (exch_slot(P, B) < 0 && (local_edge_rank(P, S, B) < LOCAL_IN_VAR) == (decltype(EARLY_)::value != 0))
-                    edge_update(S_, B_, va[S][P.blk[B].col], u[S][B]);
+                    edge_update(S_, B_, va[S][P.blk[B].col], u[S][B], BND_);
             });
         });
     };
-    auto check_local = [&]() LDPC_INLINE { local_edges(IC<0>{}); };
+    auto check_local = [&](auto BND_) LDPC_INLINE { local_edges(IC<0>{}, BND_); };
 
     // bit pattern (sign in bit 31) of the marginal of variable (S, C) of this thread
     auto marginal_bits = [&](auto S_, auto C_) LDPC_INLINE -> int {
@@ -795,7 +811,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 }
             });
         });
-        if constexpr (LEAN == 0) local_edges(IC<1>{});
+        if constexpr (LEAN == 0) local_edges(IC<1>{}, IC<0>{});      // (kernels that move local edges here have no bounded mode)
     };
 
     auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
@@ -827,12 +843,14 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
         });
         __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
-        check_local();                                                                 // (2)
+        // bounded mode = the clamp-free copy of the loop: its codewords passed the LLR range vote
+        constexpr int BND = (!CAP && NOCAP_POSSIBLE && LOCAL_IN_VAR == 0) ? 1 : 0;
+        check_local(IC<BND>{});                                                        // (2)
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], u[S][B]);
+                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], u[S][B], IC<BND>{});
             });
         });
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (4)
@@ -923,7 +941,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     static_for<J0, J1>([&](auto J_) LDPC_INLINE {
                         constexpr int J = decltype(J_)::value;
                         constexpr int B = row_block(P, Rw, J);
-                        edge_update(S_, IC<B>{}, xr[J - J0], ur[J - J0]);              // :421-425
+                        edge_update(S_, IC<B>{}, xr[J - J0], ur[J - J0], IC<0>{});     // :421-425
                         par ^= O::bits(xr[J - J0]);                                    // :445-447
                         sgn ^= O::bits(v[S][B]) & (int)0x80000000;                     // :439-441
                     });

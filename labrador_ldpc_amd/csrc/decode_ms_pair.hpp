@@ -149,25 +149,28 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             bool big = false;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 static_for<0, NTX>([&](auto C_) LDPC_INLINE {
-                    big |= !(O::mag(llr[decltype(S_)::value][decltype(C_)::value]) <= nocap_limit);   // NaN counts as big
+                    const R a = O::mag(llr[decltype(S_)::value][decltype(C_)::value]);
+                    big |= !(a <= nocap_limit) || (a != 0.0f && a < 0x1p-20f);     // NaN counts as out of range
                 });
             });
             if (__ballot(big) != 0 && (t & 63) == 0) cap_flag() = 1;
         }
     };
 
-    auto edge_update = [&](auto S_, auto B_, R x) LDPC_INLINE {
+    // BND_: the codeword passed the LLR range vote (it runs the clamp-free copy of the loop), which also makes
+    // the multiply form of the self-correction test exact (Ops<float>::self_correct_b)
+    auto edge_update = [&](auto S_, auto B_, R x, auto BND_) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         const R nv = O::sub_nv(x, u[S][B]);                                            // :421
 #ifdef LDPC_DIAG_NOSELFCORR
         v[S][B] = nv;
 #else
-        v[S][B] = O::template self_correct<true>(nv, v[S][B]);                         // :422-425
+        v[S][B] = O::template self_correct_b<(decltype(BND_)::value != 0)>(nv, v[S][B]);   // :422-425
 #endif
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
-    auto variable_phase = [&]() LDPC_INLINE {
+    auto variable_phase = [&](auto BND_) LDPC_INLINE {
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
@@ -201,7 +204,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
+                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col], BND_);
             });
         });
     };
@@ -209,6 +212,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     // ---- check phase (decoder.rs:414-450 and :391-405 of the next iteration) -------------------------
     auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
         constexpr bool CAP = decltype(CAP_)::value != 0;
+        constexpr int BND = (!CAP && NOCAP_POSSIBLE) ? 1 : 0;
         int par_any = 0;
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
@@ -248,14 +252,14 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2) local edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) >= LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col]);
+                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) >= LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col], IC<BND>{});
             });
         });
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B]);
+                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], IC<BND>{});
             });
         });
         static_for<0, NROWS>([&](auto R_) LDPC_INLINE {                                // (4) per check row, both indices
@@ -335,7 +339,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
                 else if (it == maxiters) { done = true; }
                 if (done) break;
-                variable_phase();
+                variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{});
 #ifdef LDPC_DIAG_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();

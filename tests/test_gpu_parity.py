@@ -244,3 +244,26 @@ def test_clamp_free_path_at_its_magnitude_limit(code):
             assert (ok == 0).all() and (it == maxiters).all()
             llrs[:, ::3] *= np.float32(2.0 ** -20)                  # mixed magnitudes
             _compare(code, llrs, maxiters)
+
+
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048], ids=lambda c: c.name)
+def test_bounded_mode_at_the_small_end_of_its_llr_range(code):
+    """The clamp-free copy of the f32 loop also tests the self-correction by a multiply (nv * old < 0), which is
+    exact only if no product underflows: its codewords must have every nonzero |LLR| >= 2^-20 (then every nonzero
+    value of the decode is >= 2^-43).  Frames right at that bound take the multiply form, frames with one LLR
+    below it (or denormal, or many exact zeros) the bit-operation form; all must equal the oracle."""
+    rng = np.random.default_rng(20)
+    y, _ = oracle.awgn_llrs(code, rng, 48, 2.0, np.float32)
+    mags = (np.float32(2.0 ** -20) * (1.0 + rng.random(y.shape))).astype(np.float32)      # [2^-20, 2^-19)
+    at_bound = np.copysign(mags, y).astype(np.float32)
+    _compare(code, at_bound, 25)
+    _compare(code, (y * np.float32(2.0 ** -18)).astype(np.float32), 25)                       # AWGN shape, many below the bound
+    below = at_bound.copy()
+    below[::2, 17] = np.float32(2.0 ** -21)                                                   # one LLR under the bound
+    below[1::4, 5] = np.float32(1e-42)                                                        # one denormal
+    below[3::4, ::9] = 0.0                                                                    # exact zeros are allowed in either mode
+    _compare(code, below, 25)
+    zeros = at_bound.copy()
+    zeros[:, ::3] = 0.0
+    zeros[:, 1::3] = -0.0
+    _compare(code, zeros, 25)
