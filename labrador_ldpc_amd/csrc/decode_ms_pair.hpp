@@ -78,7 +78,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     // odd rotations read their two marginals as halves of two aligned 64-bit pairs (see check_phase): +12 % for
     // i8 (8.0 -> 9.0 M codewords/s), but the wider destinations cost f32 nine spilled VGPRs (6.7 -> 6.5)
     constexpr bool ODD_B64 = LDPC_PAIR_ODD_B64 >= 0 ? LDPC_PAIR_ODD_B64 != 0 : !std::is_same_v<T, float>;
-    constexpr int LOCAL_IN_VAR = LDPC_PAIR_LOCAL_IN_VAR >= 0 ? LDPC_PAIR_LOCAL_IN_VAR : (std::is_same_v<T, float> ? 7 : 4);
+    constexpr int LOCAL_IN_VAR = LDPC_PAIR_LOCAL_IN_VAR >= 0 ? LDPC_PAIR_LOCAL_IN_VAR : (std::is_same_v<T, float> ? 8 : 4);
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
 

@@ -61,7 +61,9 @@
 // How many of the thread's local-edge updates (of 14 on TM8192) are done at the end of the variable phase
 // (LDS-bound: the VALU idles there) instead of at the start of the check phase (VALU-bound), where the
 // rest still covers the latency of the marginal reads.  f32 0/3/5/7/9/14 -> 7.04 / 7.07 / 7.24 / 7.41 /
-// 7.32 / 7.26 M codewords/s; i8 0/4/7 -> 9.29 / 9.61 / 8.31.  -1 = per type (7 for f32, 4 else).
+// 7.32 / 7.26 M codewords/s in round 1; re-swept after the multiply form of the self-correction test
+// (round 2): 5/6/7/8/9/11 -> 7.23 / 7.30 / 7.40 / 7.49 / 7.41 / 7.14; i8 3/4/5/6/7 -> 6.70 / 6.79 / 6.75 / 6.76 /
+// 6.73.  -1 = per type (8 for f32, 4 else).
 #ifndef LDPC_PAIR_LOCAL_IN_VAR
 #define LDPC_PAIR_LOCAL_IN_VAR -1
 #endif
