@@ -11,20 +11,31 @@ tmp = tempfile.mkdtemp()
 subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", os.path.join(ROOT, "build/csrc/decode_ms_f32.o"), "/dev/null"])
 subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat", f"--output={tmp}/co", "--unbundle"])
 dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", f"{tmp}/co"], text=True).split("\n")
-cur, body = None, []
+cur, body = None, []          # (address, text, branch target or None)
 for l in dis:
     m = re.match(r"^[0-9a-f]+ <(\S+)>:", l)
     if m:
         cur = m.group(1)
         continue
-    if cur and "decode_ms_pair_kernelILi8Ef" in cur:
-        body.append(l.split("//")[0].strip())
-# the iteration loop of the first quarter body: the two longest barrier-to-barrier segments that repeat
-bars = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
-segs = sorted(((b - a, a, b) for a, b in zip(bars, bars[1:])), reverse=True)
-check = next(s for s in segs)                          # longest = a check phase
-var = next(s for s in segs if s[2] == check[1])        # the segment ending where it starts = the variable phase
-loop = body[var[1]:check[2]]
+    if cur and "decode_ms_pair_kernelILi8Ef" in cur and "//" in l:
+        text, tail = l.split("//", 1)
+        addr = int(tail.split(":")[0].strip(), 16)
+        tgt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", tail)
+        body.append((addr, text.strip(), int(tgt.group(1), 16) if tgt else None))
+base = body[0][0]
+# the iteration loops are the backward branches whose span holds exactly two workgroup barriers; one per quarter
+# body and clamp mode.  Take a clamp-FREE one (no v_min_f32 cap operations, multiply-form self-correction test: the mode the
+# benchmark's frames run in).
+loops = []
+for i, (addr, text, tgt) in enumerate(body):
+    if text.startswith("s_cbranch") or text.startswith("s_branch"):
+        if tgt is not None and base + tgt < addr:
+            j = next(k for k, b in enumerate(body) if b[0] == base + tgt)
+            span = [t for _, t, _ in body[j:i + 1]]
+            if sum(1 for t in span if t.startswith("s_barrier")) == 2:
+                loops.append(span)
+loops.sort(key=lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), -sum(1 for t in sp if t.startswith("v_mul_f32")), len(sp)))
+loop = loops[0]
 FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|fma|pk_|lshl_add|lshl_or|xad)")
 cls = collections.Counter()
 ops = collections.Counter()
@@ -41,11 +52,12 @@ for l in loop:
         cls["2-cycle (plain VOP1/VOP2)"] += 1
 n = sum(cls.values())
 avg = (2 * cls["2-cycle (plain VOP1/VOP2)"] + 3 * cls["bitop3 (3 cycles)"] + 4 * cls["4-cycle (min/max/med3/compare/VOP3-only)"]) / n
-out = {"kernel": "decode_ms_pair_kernel<8, float>, quarter-0 body, one iteration (variable + check phase)",
+out = {"kernel": "decode_ms_pair_kernel<8, float>, one quarter body, clamp-free mode, one iteration (variable + check phase)",
        "valu_instructions_per_wave_iteration": n, "classes": dict(cls), "avg_issue_cycles_per_instruction": avg,
        "other": {"ds": sum(1 for l in loop if l.startswith("ds_")), "salu": sum(1 for l in loop if l.startswith("s_"))},
        "top_opcodes": ops.most_common(14),
-       "note": "static count over both clamp modes' code is avoided by taking ONE loop copy; issue costs per class from tools/ubench (valu_rate / valu_pairs, 4 waves per SIMD)"}
+       "iteration_loops_found": len(loops),
+       "note": "the loop = a backward branch spanning exactly two workgroup barriers; the clamp-free copy of one quarter body; issue costs per class from tools/ubench (valu_rate / valu_pairs, 4 waves per SIMD)"}
 os.makedirs(os.path.join(ROOT, "profiles", name), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", name, "valu_mix_tm8192_f32.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
