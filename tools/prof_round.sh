@@ -4,6 +4,7 @@
 # other BASELINE configs.   usage:  bash tools/prof_round.sh r02_final     -> gpurun_out/r02_final
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02_final}; mkdir -p $O
+rm -rf $O/trace $O/*.pmc[1-5]          # a re-run must not leave an older run's files beside the new ones
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu > $O/trace_bench.log 2>&1

@@ -6,7 +6,13 @@ import csv, glob, json, os, shutil, sys
 name = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 src, dst = f"gpurun_out/{name}", f"profiles/{name}"
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+def newest(pattern):
+    """gpurun_out/ accumulates over calls: keep only the most recent file of each kind"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(f"{src}/trace/*/*_kernel_stats.csv"):
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "ldpc::" in r[0]]
     csv.writer(open(f"{dst}/kernel_stats_bench_default.csv", "w", newline="")).writerows(keep)
@@ -19,7 +25,7 @@ traffic, allsum = {}, {}
 for tag, (frames, alg) in CONFIGS.items():
     summary = {}
     for i in range(1, 6):
-        for f in glob.glob(f"{src}/{tag}.pmc{i}/*/*_counter_collection.csv"):
+        for f in newest(f"{src}/{tag}.pmc{i}/*/*_counter_collection.csv"):
             if tag == "TM8192_f32":
                 shutil.copy(f, f"{dst}/pmc{i}_counters_{tag}.csv")
             acc = {}
