@@ -496,7 +496,19 @@ LDPC_DEV int pi_dev(int i, int j)
     constexpr int LQ = ilog2(M / 4), Q = M / 4;
     constexpr int P0 = phi_of(K, 0, M), P1 = phi_of(K, 1, M), P2 = phi_of(K, 2, M), P3 = phi_of(K, 3, M);
     constexpr int TH = theta_of(K);
-    const int phi = j == 0 ? P0 : (j == 1 ? P1 : (j == 2 ? P2 : P3));
+    int phi;
+    if constexpr (Q <= 256) {
+        // the four rotations of a block (each < Q <= 256) packed into one literal and picked by a bit-field
+        // extract: one VALU operation.  Written as a chain of selects on the per-lane quarter the compiler
+        // emitted EXEC-masked branches, one pair per quarter and edge (119 of them in the TM1280 kernel).
+        constexpr unsigned PACK = (unsigned)P0 | ((unsigned)P1 << 8) | ((unsigned)P2 << 16) | ((unsigned)P3 << 24);
+        phi = (int)__builtin_amdgcn_ubfe(PACK, (unsigned)j * 8u, 8u);
+    } else {
+        // rotations up to 16 bits: two literals, one select on bit 1 of the quarter, one bit-field extract
+        constexpr unsigned LO = (unsigned)P0 | ((unsigned)P1 << 16), HI = (unsigned)P2 | ((unsigned)P3 << 16);
+        const unsigned w = (j & 2) ? HI : LO;
+        phi = (int)__builtin_amdgcn_ubfe(w, ((unsigned)j & 1u) * 16u, 16u);
+    }
     return (((TH + j) & 3) << LQ) + ((phi + i) & (Q - 1));
 }
 
