@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 from labrador_ldpc_amd import LDPCCode
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(3)
-for name, eb, frames, dtypes in (("TM8192", 2.0, 131072, ("f32", "i8")), ("TM6144", 3.0, 131072, ("f32",)), ("TM2048", 2.5, 262144, ("f32",))):
+for name, eb, frames, dtypes in (("TM8192", 2.0, 131072, ("f32", "i8")), ("TM2048", 2.5, 262144, ("f32",))):
     code = LDPCCode[name]
     data = rng.integers(0, 256, size=(256, code.k() // 8), dtype=np.uint8)
     cws = code.encode_batch(torch.from_numpy(data).to(dev))
