@@ -1153,6 +1153,13 @@ constexpr int min_waves_per_simd()
     if (LEAN == 1) return 4;
     if (CODE == TM2048 && IPT == 1) return LDPC_TM2048_WAVES;
     if (CODE == TM1280 && IPT == 1) return 3;         // 183 -> 168 VGPRs: f32 28.4 -> 38.6, i8 27.0 -> 34.4 M codewords/s
+    // TC codes (one-wave workgroups, occupancy set by registers alone): 139-144 -> 128 VGPRs, four waves per SIMD
+    // instead of three: TC128 f32 507 -> 561, i8 478 -> 534; TC256 365 -> 391 / 349 -> 357; TC512 i8 249 -> 259 M
+    // codewords/s at 3 dB (five or six waves spill 60-100 registers and run 3-6x slower)
+    if (CODE <= TC512 && IPT == 1) return 4;
+#ifdef LDPC_MINW_CODE                                  // (tools/kbench.hip experiments)
+    if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
+#endif
     return 1;
 }
 
