@@ -208,6 +208,15 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
         return __int_as_float((__float_as_int(m) & 0x7FFFFFFF) | (s & (int)0x80000000));
     }
     LDPC_DEV static R select_zero(bool z, R x) { return z ? 0.0f : x; }
+    // x where p is not a negative non-zero number, else +0: "bits(p) <= 0x80000000" as the borrow of an integer
+    // subtraction (an I-class VOP2 operation that pairs with the F and I classes) instead of a float compare (C class)
+    LDPC_DEV static R keep_unless_negative(R p, R x)
+    {
+        R r;
+        asm("v_subrev_co_u32_e32 %0, vcc, %2, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, 0, %3, vcc"
+            : "=&v"(r) : "v"(p), "s"(0x80000001u), "v"(x) : "vcc");
+        return r;
+    }
     // Self-correction test of decoder.rs:422: drop nv iff old != 0 and sign(nv) != sign(old).
     // `old` with its sign flipped when nv is negative is a negative NON-ZERO float exactly then
     // (old is never -0.0), so one three-input bit op (old ^ (nv & 0x80000000)) and one float
@@ -219,23 +228,33 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     }
     // nv, or +0 where drop(nv, old)  (zeroing by EXEC predication instead of v_cndmask measured slower:
     // EXEC writes stall the VALU -- DESIGN.md 4.4)
-    template <bool FULL_EXEC>
-    LDPC_DEV static R self_correct(R nv, R old) { return select_zero(drop(nv, old), nv); }
+    // CARRY: the select through keep_unless_negative (chosen per kernel, see selfcorr_carry())
+    template <bool CARRY>
+    LDPC_DEV static R self_correct(R nv, R old)
+    {
+        if constexpr (CARRY) {
+            const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
+            return keep_unless_negative(__int_as_float(t), nv);
+        } else {
+            return select_zero(drop(nv, old), nv);
+        }
+    }
     // The same for codewords whose LLRs passed the range vote (BOUNDED: every |LLR| <= nocap_limit and every
     // nonzero |LLR| >= 2^-20, see begin_codeword): "old != 0 and the signs differ" is then exactly "nv * old < 0".
     // No value is infinite (the nocap bound), and every value of the decode is a multiple of g = 2^(e_min - 23),
     // e_min >= -20 the exponent of the smallest nonzero |LLR| (sums and differences of multiples of g round to
     // multiples of g), so a nonzero value is at least 2^-43 and a product of two cannot underflow; nv == 0 gives
     // v = 0 whichever way the test goes.  An F-class v_mul_f32 in place of the VOP3 bit operation: +1 %.
-    template <bool BOUNDED>
+    template <bool BOUNDED, bool CARRY = false>
     LDPC_DEV static R self_correct_b(R nv, R old)
     {
         if constexpr (BOUNDED) {
             float p;
             asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
-            return select_zero(p < 0.0f, nv);
+            if constexpr (CARRY) return keep_unless_negative(p, nv);
+            else return select_zero(p < 0.0f, nv);
         } else {
-            return select_zero(drop(nv, old), nv);
+            return self_correct<CARRY>(nv, old);
         }
     }
     // m >= 0 has bit 31 clear, so "m with sign s_all ^ s_own" is one three-input XOR of sign words
@@ -272,12 +291,12 @@ template <> struct Ops<double> {
     template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<false, false>(min2<AX, AY>(x, y), DBL_MAX); }
     template <bool AX, bool AY, bool AZ>
     LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
-    template <bool FULL_EXEC>
+    template <bool CARRY>
     LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
     {
         return (old != 0.0 && (nv < 0.0) != (old < 0.0)) ? 0.0 : nv;
     }
-    template <bool BOUNDED> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<true>(nv, old); }
+    template <bool BOUNDED, bool CARRY = false> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<false>(nv, old); }
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
         return __hiloint2double(__double2hiint(m) ^ s_all ^ s_own, __double2loint(m));
@@ -312,9 +331,18 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
         asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
         return p < 0.0f;
     }
-    template <bool FULL_EXEC>
-    LDPC_DEV static R self_correct(R nv, R old) { return Ops<float>::select_zero(drop(nv, old), nv); }
-    template <bool BOUNDED> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<true>(nv, old); }
+    template <bool CARRY>
+    LDPC_DEV static R self_correct(R nv, R old)
+    {
+        if constexpr (CARRY) {
+            float p;
+            asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
+            return Ops<float>::keep_unless_negative(p, nv);
+        } else {
+            return Ops<float>::select_zero(drop(nv, old), nv);
+        }
+    }
+    template <bool BOUNDED, bool CARRY = false> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<CARRY>(nv, old); }
     template <bool AX>
     LDPC_DEV static R min2_cap(R x)
     {
@@ -366,12 +394,12 @@ template <> struct Ops<int32_t> {
     template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<AX, AY>(x, y); }
     template <bool AX, bool AY, bool AZ>
     LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
-    template <bool FULL_EXEC>
+    template <bool CARRY>
     LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
     {
         return (old != 0 && ((nv ^ old) < 0)) ? 0 : nv;
     }
-    template <bool BOUNDED> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<true>(nv, old); }
+    template <bool BOUNDED, bool CARRY = false> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<false>(nv, old); }
     // m >= 0 negated when the product of the other edges' signs is negative (:398-405)
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
@@ -467,6 +495,18 @@ constexpr int local_in_var_default()
     // TM1536, TM1280, where several workgroups share a CU
     // (i8/i16 TM6144: 10.08 / 9.91 / 9.86 at 0 / 4 / 9 -- their variable phase carries the clamps already)
     return (CODE == TM6144 && IPT == 1 && LEAN == 0 && std::is_same_v<T, float>) ? 9 : 0;
+}
+
+// Self-correction select through an integer borrow (Ops<float>::keep_unless_negative) instead of a float compare:
+// 0 = no, 1 = the i8/i16 types, 2 = f32 as well.  Pays on the rate-4/5 codes, whose degree-18 checks make the check
+// phase the most C-class heavy (TM5120 i8 17.4 -> 18.0 at 4 dB, 7.03 -> 7.31 at 2 dB, f32 17.4 -> 18.4; TM1280 i8
+// 63.8 -> 65.2, f32 66.4 -> 67.9; TM1536 +1 % M codewords/s); neutral or negative elsewhere (TM2048 -1..-3 %,
+// TM6144 -2.5 %, TM8192 pair kernel -1.5..-3.5 %: there the compiler fills the two wait states between the VCC write
+// and the select with other work, which it cannot do inside the asm bundle).
+template <int CODE>
+constexpr int selfcorr_carry_default()
+{
+    return (CODE == TM1280 || CODE == TM1536 || CODE == TM5120) ? 2 : 0;
 }
 
 // ---- kernel geometry -----------------------------------------------------------------------
@@ -726,6 +766,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
+    constexpr int CARRY_SET = LDPC_SELFCORR_CARRY >= 0 ? LDPC_SELFCORR_CARRY : selfcorr_carry_default<CODE>();
+    constexpr bool CARRY = CARRY_SET == 2 || (CARRY_SET == 1 && !std::is_same_v<T, float>);
     auto edge_update = [&](auto S_, auto B_, R x, R uu, auto BND_) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         constexpr bool BND = decltype(BND_)::value != 0 && G == 1;
@@ -734,7 +776,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 #ifdef LDPC_DIAG_NOSELFCORR
         const R nw = nv;
 #else
-        const R nw = BND ? O::template self_correct_b<true>(nv, v[S][B]) : O::template self_correct<G == 1>(nv, v[S][B]);
+        const R nw = BND ? O::template self_correct_b<true, CARRY>(nv, v[S][B]) : O::template self_correct<CARRY>(nv, v[S][B]);
 #endif
         v[S][B] = nw;
     };
@@ -1027,7 +1069,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                             vnz = nw != O::zero() ? (vnz | bit) : (vnz & ~bit);
                             a[J] = nw;
                         } else {
-                            v[S][B] = O::template self_correct<G == 1>(nr[J - J0], v[S][B]);   // :422-425
+                            v[S][B] = O::template self_correct<false>(nr[J - J0], v[S][B]);   // :422-425
                             a[J] = v[S][B];
                         }
                         par ^= xw[J - J0];                                             // :445-447

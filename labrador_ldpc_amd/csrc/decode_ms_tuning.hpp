@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
@@ -22,6 +22,11 @@
 // workgroups spanning two or four quarters (+4.6 % on TM8192), 1 = two only, 0 = off.
 #ifndef LDPC_QUARTER_SPECIALISE
 #define LDPC_QUARTER_SPECIALISE 2
+#endif
+// Self-correction select through the borrow of an integer subtraction (I class) instead of a float compare (C class):
+// -1 = per code (selfcorr_carry_default()), 0 = off, 1 = i8/i16, 2 = f32 too.
+#ifndef LDPC_SELFCORR_CARRY
+#define LDPC_SELFCORR_CARRY -1
 #endif
 // f32: clamp-free check phase for codewords whose LLRs are bounded (NOCAP_POSSIBLE in the kernel body).
 #ifndef LDPC_NOCAP
