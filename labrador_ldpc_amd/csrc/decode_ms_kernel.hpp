@@ -212,6 +212,8 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // subtraction (an I-class VOP2 operation that pairs with the F and I classes) instead of a float compare (C class)
     LDPC_DEV static R keep_unless_negative(R p, R x)
     {
+        // (the same through __builtin_usub_overflow, which lets the compiler place the wait states, measures within
+        // +-1 % of this bundle on every kernel)
         R r;
         asm("v_subrev_co_u32_e32 %0, vcc, %2, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, 0, %3, vcc"
             : "=&v"(r) : "v"(p), "s"(0x80000001u), "v"(x) : "vcc");

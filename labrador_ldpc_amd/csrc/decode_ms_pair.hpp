@@ -165,7 +165,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #ifdef LDPC_DIAG_NOSELFCORR
         v[S][B] = nv;
 #else
-        v[S][B] = O::template self_correct_b<(decltype(BND_)::value != 0)>(nv, v[S][B]);   // :422-425
+        v[S][B] = O::template self_correct_b<(decltype(BND_)::value != 0), (LDPC_PAIR_SELFCORR_CARRY != 0)>(nv, v[S][B]);   // :422-425
 #endif
     };
 
