@@ -28,7 +28,10 @@ namespace ldpc {
 
 #ifdef LDPC_DIAG_STAMPS
 // per wave: cycles in [variable phase, wait at barrier 2, check phase, wait at barrier 1], summed over iterations
-__device__ unsigned long long g_stamps[256 * 16 * 4];
+// [4] = ticks from the first begin_codeword to the end of the last epilogue, [5] = the same in s_memrealtime (100 MHz) ticks
+__device__ unsigned long long g_stamps[256 * 16 * 6];
+// absolute s_memrealtime at workgroup entry / at the start of the codeword loop / at exit, last launch only
+__device__ unsigned long long g_wg_times[256 * 3];
 #endif
 
 typedef float ldpc_f2 __attribute__((ext_vector_type(2)));
@@ -316,9 +319,15 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- persistent loop over codewords ----------------------------------------------------------------
+#ifdef LDPC_DIAG_STAMPS
+    if (t == 0 && blockIdx.x < 256) g_wg_times[blockIdx.x * 3] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (t == 0) cap_flag() = 0;
     LDPC_SYNC();
     if (blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
+#ifdef LDPC_DIAG_STAMPS
+    const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime(), loop_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
         cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         (void)first;                              // (this codeword's LLR loads were issued behind the previous epilogue)
@@ -366,7 +375,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         }
 #ifdef LDPC_DIAG_STAMPS
         if ((t & 63) == 0 && blockIdx.x < 256) {
-            unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 4;
+            unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 6;
             d[0] += acc_var; d[1] += acc_w2; d[2] += acc_chk; d[3] += acc_w1;
         }
 #endif
@@ -399,6 +408,13 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         if (t == 0) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; cap_flag() = 0; }
         LDPC_SYNC();
     }
+#ifdef LDPC_DIAG_STAMPS
+    if ((t & 63) == 0 && blockIdx.x < 256) {
+        unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 6;
+        d[4] += __builtin_amdgcn_s_memtime() - loop_t0; d[5] += __builtin_amdgcn_s_memrealtime() - loop_r0;
+        if (t == 0) { g_wg_times[blockIdx.x * 3 + 1] = loop_r0; g_wg_times[blockIdx.x * 3 + 2] = __builtin_amdgcn_s_memrealtime(); }
+    }
+#endif
 }
 
 template <int CODE, class T>

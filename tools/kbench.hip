@@ -75,13 +75,35 @@ int main()
     for (size_t i = 0; i < F * ol; ++i) h = (h ^ ho[i]) * 1099511628211ull;
 #ifdef LDPC_DIAG_STAMPS
     {
-        std::vector<unsigned long long> st(256 * 16 * 4);
+        std::vector<unsigned long long> st(256 * 16 * 6);
         CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(ldpc::g_stamps), st.size() * 8));
-        double tot[4] = {0, 0, 0, 0}, perq[4][4] = {};
-        for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) for (int k = 0; k < 4; ++k) { tot[k] += st[(b * 16 + w) * 4 + k]; perq[w / 4][k] += st[(b * 16 + w) * 4 + k]; }
-        const double iters_total = (si + F) * 5.0;     // 5 launches accumulated (1 warm + 4 timed); + F: the final verdict pass
+        double tot[6] = {0, 0, 0, 0, 0, 0}, perq[4][6] = {};
+        for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) for (int k = 0; k < 6; ++k) { tot[k] += st[(b * 16 + w) * 6 + k]; perq[w / 4][k] += st[(b * 16 + w) * 6 + k]; }
+        const double launches = 4.0;                       // the rep loop above: 1 warm + 3 timed launches accumulate
+        const double iters_total = (si + F) * launches;    // + F: the final verdict pass
         printf("stamps (s_memtime ticks per wave and iteration, all launches): variable %.0f | wait2 %.0f | check %.0f | wait1 %.0f\n",
                tot[0] / 4096 / (iters_total / 256) , tot[1] / 4096 / (iters_total / 256), tot[2] / 4096 / (iters_total / 256), tot[3] / 4096 / (iters_total / 256));
+        printf("  whole codeword loop: %.0f s_memtime ticks per codeword, of which %.0f inside the iterations (%.1f %%); shader clock %.0f MHz (s_memtime against the 100 MHz s_memrealtime)\n",
+               tot[4] / 4096 / (launches * F / 256), (tot[0] + tot[1] + tot[2] + tot[3]) / 4096 / (launches * F / 256), 100.0 * (tot[0] + tot[1] + tot[2] + tot[3]) / tot[4], 100.0 * tot[4] / tot[5]);
+        {
+            double mx = 0, mn = 1e30, mxr = 0, mnr = 1e30;
+            for (int b = 0; b < 256; ++b) {
+                const double v = st[(b * 16) * 6 + 4] / launches, r = st[(b * 16) * 6 + 5] / launches;
+                mx = v > mx ? v : mx; mn = v < mn ? v : mn; mxr = r > mxr ? r : mxr; mnr = r < mnr ? r : mnr;
+            }
+            printf("  per workgroup and launch: codeword loop %.0f .. %.0f s_memtime ticks, %.3f .. %.3f ms by s_memrealtime\n", mn, mx, mnr / 1e5, mxr / 1e5);
+        }
+        {
+            std::vector<unsigned long long> wt(256 * 3);
+            CK(hipMemcpyFromSymbol(wt.data(), HIP_SYMBOL(ldpc::g_wg_times), wt.size() * 8));
+            unsigned long long e0 = ~0ull, e1 = 0, l0 = 0, x0 = ~0ull, x1 = 0;
+            for (int b = 0; b < 256; ++b) {
+                e0 = wt[b * 3] < e0 ? wt[b * 3] : e0; e1 = wt[b * 3] > e1 ? wt[b * 3] : e1; l0 = wt[b * 3 + 1] > l0 ? wt[b * 3 + 1] : l0;
+                x0 = wt[b * 3 + 2] < x0 ? wt[b * 3 + 2] : x0; x1 = wt[b * 3 + 2] > x1 ? wt[b * 3 + 2] : x1;
+            }
+            printf("  last launch, s_memrealtime relative to the first workgroup's entry: last entry %.3f ms, last loop start %.3f ms, first exit %.3f ms, last exit %.3f ms\n",
+                   (e1 - e0) / 1e5, (l0 - e0) / 1e5, (x0 - e0) / 1e5, (x1 - e0) / 1e5);
+        }
         for (int q = 0; q < 4; ++q)
             printf("  quarter %d waves: variable %.0f | wait2 %.0f | check %.0f | wait1 %.0f\n", q, perq[q][0] / 1024 / (iters_total / 256), perq[q][1] / 1024 / (iters_total / 256),
                    perq[q][2] / 1024 / (iters_total / 256), perq[q][3] / 1024 / (iters_total / 256));
