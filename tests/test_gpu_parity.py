@@ -70,8 +70,8 @@ def test_i32_parity(code):
         _compare(code, llrs, 6, variant=variant)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TC512, LDPCCode.TM1280, LDPCCode.TM2048, LDPCCode.TM8192],
-                         ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TC512, LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048, LDPCCode.TM5120,
+                                  LDPCCode.TM8192], ids=lambda c: c.name)
 def test_saturating_i8(code):
     """Full-scale i8 LLRs (+-127, -128): saturating add/sub/abs paths (src/decoder.rs:42-50)."""
     rng = np.random.default_rng(7 + int(code))
@@ -80,9 +80,10 @@ def test_saturating_i8(code):
     _compare(code, llrs, 20)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TC256, LDPCCode.TM1536, LDPCCode.TM8192], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TC256, LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM5120, LDPCCode.TM8192], ids=lambda c: c.name)
 def test_f32_corner_values(code):
-    """Zeros, signed zeros, denormals, huge and infinite LLRs."""
+    """Zeros, signed zeros, denormals, huge and infinite LLRs.  (TM1280 / TM1536 / TM5120 take the self-correction
+    select through an integer borrow, Ops<float>::keep_unless_negative; TM5120 on the register-lean kernel.)"""
     rng = np.random.default_rng(11 + int(code))
     llrs, _ = oracle.awgn_llrs(code, rng, 64, 3.0, np.float32)
     n = code.n()
