@@ -627,7 +627,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // nocap_limit_for() in decode_ms_launch.hpp) nothing can, and the check phase runs without the clamp
     // operations (TM8192 pair kernel +3 %).  The vote is one LDS word per codeword.
     // Measured: TM2048 41.3 -> 43.0 M codewords/s; TM6144 -1.6 %, TM1536 -0.7 %, TM1280 -11 %, and 34 spilled VGPRs
-    // with two indices per thread (the second copy of the loop is not free), hence TM2048 only.
+    // with two indices per thread (the second copy of the loop is not free); TC512: 19 spilled VGPRs at the four-waves budget,
+    // 108 -> 100 M codewords/s on config 2.  Hence TM2048 only.
     constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && CODE == TM2048 && G == 1 && LEAN == 0 && IPT == 1;
     auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(gbase + FLAG_OFF + 8); };
 
