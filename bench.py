@@ -181,6 +181,9 @@ def run_rank(args):
     # one GPU per rank: local rank r uses device r, unless --devices maps ranks to ordinals explicitly (testing
     # the N > 1 path on a box with fewer GPUs: "--gpus 2 --devices 0,0")
     ordinal = int(args.devices.split(",")[local_rank]) if args.devices else local_rank
+    masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if not args.devices and masked and torch.cuda.device_count() == 1:
+        ordinal = 0                       # a launcher that gives every rank its own visible device
     if ordinal >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: device {ordinal} requested, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(ordinal)

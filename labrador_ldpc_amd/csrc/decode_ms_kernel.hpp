@@ -1194,17 +1194,19 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 template <int CODE, class T, int IPT, int LEAN>
 constexpr int min_waves_per_simd()
 {
+#ifdef LDPC_MINW_CODE                                  // (tools/kbench.hip experiments)
+    if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
+#endif
     if (sizeof(T) > 4) return 1;
     if (LEAN == 1) return 4;
     if (CODE == TM2048 && IPT == 1) return LDPC_TM2048_WAVES;
     if (CODE == TM1280 && IPT == 1) return 3;         // 183 -> 168 VGPRs: f32 28.4 -> 38.6, i8 27.0 -> 34.4 M codewords/s
     // TC codes (one-wave workgroups, occupancy set by registers alone): 139-144 -> 128 VGPRs, four waves per SIMD
     // instead of three: TC128 f32 507 -> 561, i8 478 -> 534; TC256 365 -> 391 / 349 -> 357; TC512 i8 249 -> 259 M
-    // codewords/s at 3 dB (five or six waves spill 60-100 registers and run 3-6x slower)
-    if (CODE <= TC512 && IPT == 1) return 4;
-#ifdef LDPC_MINW_CODE                                  // (tools/kbench.hip experiments)
-    if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
-#endif
+    // codewords/s at 3 dB (five or six waves spill 60-100 registers and run 3-6x slower).  Not TC256 / TC512 i8 and
+    // i16: the 10-24 registers they spill at 128 sit in the prologue and epilogue, which at 5 dB (2 iterations) is most
+    // of a decode: TC256 i8 791 -> 636, TC512 i8 451 -> 434 M codewords/s there, for +2 % / +6 % at 3 dB.
+    if (CODE <= TC512 && IPT == 1 && !(CODE >= TC256 && sizeof(T) < 4)) return 4;
     return 1;
 }
 
