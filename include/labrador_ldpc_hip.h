@@ -295,6 +295,27 @@ int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code code, const uint8_t *i
 int labrador_ldpc_encode_batch(enum labrador_ldpc_code code, const uint8_t *data, uint8_t *codewords,
                                size_t batch, const struct labrador_ldpc_hip_opts *opts);
 
+/* Batched LLR helpers: the data formats either side of decode_ms for whole batches -- hard_to_llrs
+ * (src/decoder.rs:484-493; per-frame C entries capi/src/lib.rs:129-153) and llrs_to_hard (src/decoder.rs:498-509;
+ * capi/src/lib.rs:155-179), frame after frame:
+ *   input / output  [batch][n/8]  packed bits, MSB first
+ *   llrs            [batch][n]    -1 for a set bit, +1 for a clear one; a bit is set where the LLR is < 0
+ * With opts->memory == MEM_DEVICE the conversion is a streaming kernel on opts->stream (asynchronous; llrs
+ * 16-byte aligned), so that hard decisions produced on the device (encode_batch, decode_bf_batch,
+ * a decode_ms_batch output) feed decode_ms_batch without leaving HBM.  With host buffers (opts NULL or MEM_HOST) the
+ * frames are converted in place by the library's host code -- the data is there and the loop is cheaper than the PCIe
+ * crossing; opts->device / devices are ignored.  Returns a status code. */
+int labrador_ldpc_hard_to_llrs_batch_i8 (enum labrador_ldpc_code code, const uint8_t *input, int8_t  *llrs, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_hard_to_llrs_batch_i16(enum labrador_ldpc_code code, const uint8_t *input, int16_t *llrs, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_hard_to_llrs_batch_i32(enum labrador_ldpc_code code, const uint8_t *input, int32_t *llrs, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_hard_to_llrs_batch_f32(enum labrador_ldpc_code code, const uint8_t *input, float   *llrs, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_hard_to_llrs_batch_f64(enum labrador_ldpc_code code, const uint8_t *input, double  *llrs, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_llrs_to_hard_batch_i8 (enum labrador_ldpc_code code, const int8_t  *llrs, uint8_t *output, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_llrs_to_hard_batch_i16(enum labrador_ldpc_code code, const int16_t *llrs, uint8_t *output, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_llrs_to_hard_batch_i32(enum labrador_ldpc_code code, const int32_t *llrs, uint8_t *output, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_llrs_to_hard_batch_f32(enum labrador_ldpc_code code, const float   *llrs, uint8_t *output, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_llrs_to_hard_batch_f64(enum labrador_ldpc_code code, const double  *llrs, uint8_t *output, size_t batch, const struct labrador_ldpc_hip_opts *opts);
+
 /* Synthetic AWGN frames on the device (harness side of the path; what perftest's ms_trial does
  * per frame at perftest/src/main.rs:10-18, batched): frame f takes codeword (f mod pool) of
  * `codewords` ([pool][n/8] bytes, MSB first), maps bit b to 1-2b, adds sigma*N(0,1) from a

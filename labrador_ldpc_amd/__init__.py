@@ -75,6 +75,8 @@ SYMBOLS = {
     "labrador_ldpc_decode_ms_batch_f64": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_bf_batch": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_encode_batch": (_int, [_int, _vp, _vp, _sz, _optp]),
+    **{f"labrador_ldpc_hard_to_llrs_batch_{t}": (_int, [_int, _vp, _vp, _sz, _optp]) for t in ("i8", "i16", "i32", "f32", "f64")},
+    **{f"labrador_ldpc_llrs_to_hard_batch_{t}": (_int, [_int, _vp, _vp, _sz, _optp]) for t in ("i8", "i16", "i32", "f32", "f64")},
     "labrador_ldpc_hip_awgn_f32": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_uint64, _optp]),
     "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
                                          _c.c_uint64, _optp]),
@@ -439,6 +441,65 @@ class LDPCCode(enum.IntEnum):
         _check_result_buffer(codewords, data, (batch, self.n() // 8), "u8", "codewords")
         _check(lib.labrador_ldpc_encode_batch(int(self), _ptr(data), _ptr(codewords), batch, ctypes.byref(opts)))
         return codewords
+
+    # ---- LLR helpers, batched (src/decoder.rs:484-509 frame after frame) ----
+    def hard_to_llrs_batch(self, input, dtype="f32", llrs=None, stream: Optional[int] = None):
+        """input[batch, n/8] packed bits -> llrs[batch, n] of +-1 (`dtype`: "i8", "i16", "i32", "f32", "f64").
+        torch CUDA uint8 tensor = on the device, asynchronous on the stream; numpy = host code."""
+        if input.ndim != 2 or input.shape[1] != self.n() // 8:
+            raise ValueError("input must be [batch, n/8]")
+        batch = input.shape[0]
+        if _is_torch(input):
+            import torch
+            tdt = {"f32": torch.float32, "i8": torch.int8, "i16": torch.int16, "i32": torch.int32, "f64": torch.float64}[dtype]
+            if not (input.is_cuda and input.dtype == torch.uint8 and input.is_contiguous()):
+                raise ValueError("input must be a contiguous uint8 CUDA tensor")
+            dev = input.device
+            if llrs is None:
+                llrs = torch.empty((batch, self.n()), dtype=tdt, device=dev)
+            elif not (_is_torch(llrs) and llrs.device == dev and llrs.dtype == tdt and tuple(llrs.shape) == (batch, self.n())
+                      and llrs.is_contiguous()):
+                raise ValueError(f"llrs must be a contiguous {tdt} tensor of shape ({batch}, {self.n()}) on {dev}")
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0, 0, None)
+        else:
+            ndt = {v: k for k, v in _NP_SUFFIX.items()}[dtype]
+            input = np.ascontiguousarray(input, dtype=np.uint8)
+            if llrs is None:
+                llrs = np.empty((batch, self.n()), dtype=ndt)
+            elif not (isinstance(llrs, np.ndarray) and llrs.dtype == ndt and llrs.shape == (batch, self.n())
+                      and llrs.flags.c_contiguous and llrs.flags.writeable):
+                raise ValueError(f"llrs must be a writable C-contiguous {ndt} array of shape ({batch}, {self.n()})")
+            opts = HipOpts(DEVICE_CURRENT, MEM_HOST, None, 0, 0, None)
+        _check(getattr(lib, "labrador_ldpc_hard_to_llrs_batch_" + dtype)(int(self), _ptr(input), _ptr(llrs), batch, ctypes.byref(opts)))
+        return llrs
+
+    def llrs_to_hard_batch(self, llrs, output=None, stream: Optional[int] = None):
+        """llrs[batch, n] -> output[batch, n/8] packed hard decisions (bit set where the LLR is < 0)."""
+        if llrs.ndim != 2 or llrs.shape[1] != self.n():
+            raise ValueError("llrs must be [batch, n]")
+        batch = llrs.shape[0]
+        if _is_torch(llrs):
+            import torch
+            if not (llrs.is_cuda and llrs.is_contiguous()):
+                raise ValueError("llrs must be a contiguous CUDA tensor")
+            dev = llrs.device
+            if output is None:
+                output = torch.empty((batch, self.n() // 8), dtype=torch.uint8, device=dev)
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0, 0, None)
+        else:
+            if llrs.dtype not in _NP_SUFFIX:
+                raise ValueError("llrs dtype must be one of int8, int16, int32, float32, float64")
+            llrs = np.ascontiguousarray(llrs)
+            if output is None:
+                output = np.empty((batch, self.n() // 8), dtype=np.uint8)
+            opts = HipOpts(DEVICE_CURRENT, MEM_HOST, None, 0, 0, None)
+        _check_result_buffer(output, llrs, (batch, self.n() // 8), "u8", "output")
+        _check(getattr(lib, "labrador_ldpc_llrs_to_hard_batch_" + _suffix(llrs))(int(self), _ptr(llrs), _ptr(output), batch, ctypes.byref(opts)))
+        return output
 
     # ---- synthetic channel (harness) ----
     def awgn_frames(self, codewords, batch: int, sigma: float, seed: int, dtype="f32",

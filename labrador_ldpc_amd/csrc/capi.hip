@@ -23,6 +23,7 @@
 #include "channel.hpp"
 #include "encode.hpp"
 #include "decode_bf.hpp"
+#include "llr_convert.hpp"
 #include "codes.hpp"
 #include "host_codes.hpp"
 
@@ -576,6 +577,52 @@ void llrs_to_hard(int code, const T *llrs, uint8_t *output)
         if (llrs[i] < (T)0) output[i / 8] |= (uint8_t)(0x80u >> (i % 8));
 }
 
+// Batched forms.  Host buffers are converted where they lie, by the loops above (the data is on the host and the
+// conversion is cheaper than the PCIe crossing); device buffers by the streaming kernels of llr_convert.hip, on
+// opts->stream, asynchronously -- so that hard decisions produced on the device (decode_bf_batch / decode_ms_batch
+// outputs, encode_batch codewords) reach decode_ms_batch without leaving HBM.
+template <class T>
+int hard_to_llrs_batch(int code, const uint8_t *input, T *llrs, size_t batch, const labrador_ldpc_hip_opts *opts)
+{
+    g_err.clear();
+    if (!ldpc::valid_code(code)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", code);
+    if (batch == 0) return LABRADOR_LDPC_HIP_OK;
+    if (!input || !llrs) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
+    const size_t n = ldpc::CODES[code].n;
+    if (!opts || opts->memory == LABRADOR_LDPC_HIP_MEM_HOST) {
+        for (size_t f = 0; f < batch; ++f) hard_to_llrs(code, input + f * (n / 8), llrs + f * n);
+        return LABRADOR_LDPC_HIP_OK;
+    }
+    if (opts->memory != LABRADOR_LDPC_HIP_MEM_DEVICE) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
+    if ((uintptr_t)llrs % 16) return fail(LABRADOR_LDPC_HIP_EINVAL, "device llrs buffer must be 16-byte aligned");
+    DeviceScope scope;
+    if (int s = scope.enter(opts)) return s;
+    hipError_t e = ldpc::launch_hard_to_llrs<T>(input, llrs, batch * (n / 8), (hipStream_t)opts->stream);
+    if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "hard_to_llrs launch: %s", hipGetErrorString(e));
+    return LABRADOR_LDPC_HIP_OK;
+}
+
+template <class T>
+int llrs_to_hard_batch(int code, const T *llrs, uint8_t *output, size_t batch, const labrador_ldpc_hip_opts *opts)
+{
+    g_err.clear();
+    if (!ldpc::valid_code(code)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", code);
+    if (batch == 0) return LABRADOR_LDPC_HIP_OK;
+    if (!llrs || !output) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
+    const size_t n = ldpc::CODES[code].n;
+    if (!opts || opts->memory == LABRADOR_LDPC_HIP_MEM_HOST) {
+        for (size_t f = 0; f < batch; ++f) llrs_to_hard(code, llrs + f * n, output + f * (n / 8));
+        return LABRADOR_LDPC_HIP_OK;
+    }
+    if (opts->memory != LABRADOR_LDPC_HIP_MEM_DEVICE) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad opts->memory");
+    if ((uintptr_t)llrs % 16) return fail(LABRADOR_LDPC_HIP_EINVAL, "device llrs buffer must be 16-byte aligned");
+    DeviceScope scope;
+    if (int s = scope.enter(opts)) return s;
+    hipError_t e = ldpc::launch_llrs_to_hard<T>(llrs, output, batch * (n / 8), (hipStream_t)opts->stream);
+    if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "llrs_to_hard launch: %s", hipGetErrorString(e));
+    return LABRADOR_LDPC_HIP_OK;
+}
+
 template <class T>
 int awgn(int code, const uint8_t *codewords, size_t pool, T *llrs, size_t batch, float sigma, float scale,
          int lim, uint64_t seed, const labrador_ldpc_hip_opts *opts)
@@ -706,6 +753,18 @@ void labrador_ldpc_llrs_to_hard_i16(enum labrador_ldpc_code c, const int16_t *ll
 void labrador_ldpc_llrs_to_hard_i32(enum labrador_ldpc_code c, const int32_t *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
 void labrador_ldpc_llrs_to_hard_f32(enum labrador_ldpc_code c, const float *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
 void labrador_ldpc_llrs_to_hard_f64(enum labrador_ldpc_code c, const double *llrs, uint8_t *out) { llrs_to_hard(c, llrs, out); }
+
+#define LDPC_LLR_BATCH(SUF, T) \
+    int labrador_ldpc_hard_to_llrs_batch_##SUF(enum labrador_ldpc_code c, const uint8_t *in, T *llrs, size_t batch, \
+                                               const struct labrador_ldpc_hip_opts *opts) { return hard_to_llrs_batch<T>(c, in, llrs, batch, opts); } \
+    int labrador_ldpc_llrs_to_hard_batch_##SUF(enum labrador_ldpc_code c, const T *llrs, uint8_t *out, size_t batch, \
+                                               const struct labrador_ldpc_hip_opts *opts) { return llrs_to_hard_batch<T>(c, llrs, out, batch, opts); }
+LDPC_LLR_BATCH(i8, int8_t)
+LDPC_LLR_BATCH(i16, int16_t)
+LDPC_LLR_BATCH(i32, int32_t)
+LDPC_LLR_BATCH(f32, float)
+LDPC_LLR_BATCH(f64, double)
+#undef LDPC_LLR_BATCH
 
 // ---- batched GPU decoders ----------------------------------------------------------------------
 int labrador_ldpc_decode_ms_batch_f32(enum labrador_ldpc_code c, const float *llrs, uint8_t *output, uint32_t *iters,

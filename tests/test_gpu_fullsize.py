@@ -39,16 +39,10 @@ def _pool(code, count, seed):
 
 
 def _hard_llrs(code, out, dtype):
-    """+-1 LLRs from packed output bits (MSB first), on the device, in chunks."""
-    n = code.n()
-    B = out.shape[0]
-    llrs = torch.empty((B, n), dtype=torch.float32 if dtype == "f32" else torch.int8, device=out.device)
-    shifts = torch.arange(7, -1, -1, device=out.device, dtype=torch.uint8)
-    step = 65536
-    for s in range(0, B, step):
-        bits = (out[s:s + step, : n // 8, None] >> shifts) & 1
-        llrs[s:s + step] = (1 - 2 * bits.reshape(-1, n).to(torch.int8)).to(llrs.dtype)
-    return llrs
+    """+-1 LLRs from packed output bits (MSB first), on the device: the library's batched hard_to_llrs
+    (labrador_ldpc_hard_to_llrs_batch_*, src/decoder.rs:484-493 frame after frame) over the first n/8 bytes."""
+    bits = out[:, : code.n() // 8].contiguous()
+    return code.hard_to_llrs_batch(bits, dtype)
 
 
 @pytest.mark.parametrize("code,dtype,frames,ebn0", CONFIGS)
