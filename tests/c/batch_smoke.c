@@ -48,6 +48,24 @@ int main(int argc, char **argv)
             llrs[f * n + i] = (int8_t)v;
         }
 
+    /* batched LLR helpers (host buffers): hard decisions of the LLRs differ from the codewords in exactly the burst */
+    {
+        int8_t *pm1 = malloc(frames * n);
+        uint8_t *hard = malloc(frames * n / 8);
+        CHECK(pm1 && hard, "malloc");
+        CHECK(labrador_ldpc_hard_to_llrs_batch_i8(code, cws, pm1, frames, NULL) == LABRADOR_LDPC_HIP_OK, "hard_to_llrs_batch");
+        CHECK(labrador_ldpc_llrs_to_hard_batch_i8(code, pm1, hard, frames, NULL) == LABRADOR_LDPC_HIP_OK, "llrs_to_hard_batch");
+        CHECK(memcmp(hard, cws, frames * n / 8) == 0, "hard_to_llrs_batch / llrs_to_hard_batch do not round-trip");
+        int8_t single_frame[LABRADOR_LDPC_N(CODE)];
+        labrador_ldpc_hard_to_llrs_i8(code, cws + probe * (n / 8), single_frame);
+        CHECK(memcmp(single_frame, pm1 + probe * n, n) == 0, "hard_to_llrs_batch != hard_to_llrs");
+        CHECK(labrador_ldpc_llrs_to_hard_batch_i8(code, llrs, hard, frames, NULL) == LABRADOR_LDPC_HIP_OK, "llrs_to_hard_batch");
+        size_t wrong = 0;
+        for (size_t i = 0; i < frames * n / 8; i++) wrong += (size_t)__builtin_popcount(hard[i] ^ cws[i]);
+        CHECK(wrong == 6 * frames, "%zu wrong hard decisions, expected %zu", wrong, 6 * frames);
+        free(pm1); free(hard);
+    }
+
     struct labrador_ldpc_hip_opts single = {0};                         /* device 0, host memory, default stream */
     CHECK(labrador_ldpc_decode_ms_batch_i8(code, llrs, out1, it1, ok1, frames, 25, &single) == 0, "decode on device 0");
     size_t good = 0;
