@@ -114,6 +114,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     T lraw[IPT][NTX];
 
     auto fetch_llrs = [&](uint32_t c) LDPC_INLINE {
+#ifdef LDPC_DIAG_NOFETCH
+        if (c != blockIdx.x) return;             // (timing diagnostic: every codeword of a workgroup re-uses the first one's LLRs)
+#endif
         unsigned tu = (unsigned)t;
         asm volatile("" : "+v"(tu));
         const uint32_t cc = c < batch ? c : batch - 1;
@@ -139,15 +142,18 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
             static_for<0, NTX>([&](auto C_) LDPC_INLINE { llr[S][decltype(C_)::value] = O::load(lraw[S][decltype(C_)::value]); });
         });
+#ifndef LDPC_DIAG_NOZERO
         static_for<0, NX>([&](auto X_) LDPC_INLINE {                                   // u = 0 in every exchange slot
             lds2(lds_xu_off(P, decltype(X_)::value, BLK_BYTES) + tb8) = ldpc_f2{0.0f, 0.0f};
         });
+#endif
         if (t < 2) flag_at(t) = 0;
         // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
         // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
         // |LLR| <= nocap_limit (derived from max_iters by the host: nocap_limit_for(), decode_ms_launch.hpp)
         // nothing can, and the check phase runs without the clamp operations (8 of 76 min-class
         // instructions per thread and iteration).
+#ifndef LDPC_DIAG_NOVOTE
         if constexpr (NOCAP_POSSIBLE) {
             bool big = false;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
@@ -158,6 +164,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             });
             if (__ballot(big) != 0 && (t & 63) == 0) cap_flag() = 1;
         }
+#endif
     };
 
     // BND_: the codeword passed the LLR range vote (it runs the clamp-free copy of the loop), which also makes
@@ -384,6 +391,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
         // s_bitreplicate doubles every bit), then bit-reversed per byte
+#ifdef LDPC_DIAG_NOPACK
+        if (maxiters == 0x7FFFFFFF)
+#endif
         static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
             constexpr int C = decltype(C_)::value;
             const unsigned long long ev = __ballot(O::bits(va[0][C]) < 0), od = __ballot(O::bits(va[1][C]) < 0);

@@ -9,7 +9,7 @@
 
 #ifndef LDPC_KBENCH
 #if defined(LDPC_DIAG_NOBARRIER) || defined(LDPC_DIAG_FIXED_ITERS) || defined(LDPC_DIAG_NOLDS) || defined(LDPC_DIAG_NOSELFCORR) || \
-    defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
+    defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
     defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_PAIR_SELFCORR_CARRY)
@@ -93,5 +93,5 @@
 #endif
 // Diagnostics (LDPC_KBENCH only, wrong or perturbed results): LDPC_DIAG_NOBARRIER, LDPC_DIAG_NOLDS,
 // LDPC_DIAG_NOMIN, LDPC_DIAG_NOSELFCORR, LDPC_DIAG_NOSIGN, LDPC_DIAG_NOPAR (leave an instruction group out: what does it
-// cost?), LDPC_DIAG_FIXED_ITERS (no early exit),
+// cost?), LDPC_DIAG_NOFETCH / NOPACK / NOVOTE / NOZERO (the same for the per-codeword prologue and epilogue), LDPC_DIAG_FIXED_ITERS (no early exit),
 // LDPC_DIAG_STAMPS (per-phase s_memtime sums).
