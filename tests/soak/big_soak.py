@@ -1,5 +1,5 @@
 """Wide parity soak: every code x LLR type, several operating points, GPU vs the oracle.
-    python tools/big_soak.py [multiplier]      (1 = 255 000 frames, ~75 s on the GPU box, almost all of it the CPU oracle)"""
+    python tests/soak/big_soak.py [multiplier]      (1 = 255 000 frames, ~75 s on the GPU box, almost all of it the CPU oracle)"""
 import sys, time, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import oracle

@@ -5,7 +5,7 @@ cd $R
 bash tools/prof_round.sh $N > $O/prof_round.log 2>&1
 python3 tools/rates_all.py > $O/rates_all_codes.txt 2> $O/rates_all_codes.err
 bash tools/kb_analysis.sh > $O/kbench_analysis.txt 2>&1
-python3 tools/big_soak.py > $O/big_soak.txt 2>&1
+python3 tests/soak/big_soak.py > $O/big_soak.txt 2>&1
 python3 tools/enc_bench.py > $O/encoder_rates.txt 2>&1
 python3 tools/hp_sweep.py > $O/host_path_rates.txt 2>&1
 S=0.6,0.8,1.0,1.2,1.4,1.6,1.8,2.0,2.5,3.0,3.5,4.0
