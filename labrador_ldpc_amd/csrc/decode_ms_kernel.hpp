@@ -871,7 +871,16 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if constexpr (LEAN == 0) local_edges(IC<1>{}, IC<0>{});      // (kernels that move local edges here have no bounded mode)
     };
 
-    auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
+    // Codewords that live inside ONE wave (the TC codes: 16 / 32 / 64 threads each) get their verdict without a
+    // barrier: the parity of every owned check (decoder.rs:445-447) is evaluated as soon as the exchanged marginals
+    // have arrived, one ballot tells every lane whether all checks of its codeword hold (decoder.rs:453), and if
+    // they do the rest of the check phase -- the updates, minima and messages of an iteration whose result nobody
+    // reads -- is skipped.  A success that takes k iterations then costs k + 0.35 passes instead of k + 1: +10-20 % at
+    // 5 dB (2 iterations), +1-12 % at 3 dB (min_waves_per_simd() has the table); config 2 (TC512 f32 at 2 dB, 15
+    // iterations, 29 % failures) 108 -> 105.5.  Multi-wave codewords would need one more barrier per iteration for
+    // this, which costs more than the last half pass.
+    constexpr bool WAVE_VERDICT = LDPC_WAVE_VERDICT && GEO::WG == 64 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
+    auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE -> bool {
         constexpr bool CAP = decltype(CAP_)::value != 0;
         // decoder.rs:414-450, and :391-405 of the NEXT iteration
         int par_any = 0;          // bit 31 set if any owned check has odd parity
@@ -900,6 +909,27 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
         });
         __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
+        if constexpr (WAVE_VERDICT) {
+            int pe = 0;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value;
+                static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
+                    constexpr int Rw = decltype(R_)::value;
+                    constexpr int D = row_degree(P, Rw);
+                    int xw[D];
+                    static_for<0, D>([&](auto J_) LDPC_INLINE {
+                        constexpr int J = decltype(J_)::value;
+                        constexpr int B = row_block(P, Rw, J);
+                        if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
+                        else xw[J] = O::bits(va[S][P.blk[B].col]);
+                    });
+                    pe |= xor_reduce<D>(xw);
+                });
+            });
+            const unsigned long long odd = __ballot(pe < 0);                            // lanes with an unsatisfied check
+            constexpr unsigned long long GROUP = NT >= 64 ? ~0ull : ((1ull << (NT & 63)) - 1ull);
+            if (((odd >> (grp * NT)) & GROUP) == 0) return true;                        // :453
+        }
         // bounded mode = the clamp-free copy of the loop: its codewords passed the LLR range vote
         constexpr int BND = (!CAP && NOCAP_POSSIBLE && LOCAL_IN_VAR == 0) ? 1 : 0;
         check_local(IC<BND>{});                                                        // (2)
@@ -932,7 +962,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
-                const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
+                const int sgn = xor_reduce<D>(sr), par = WAVE_VERDICT ? 0 : xor_reduce<D>(xw);
 #ifdef LDPC_DIAG_NOMIN
                 static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = O::mag(a[decltype(J_)::value]); });
 #else
@@ -952,7 +982,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 par_any |= par;
             });
         });
+        if constexpr (WAVE_VERDICT) return false;       // (some check of this codeword is unsatisfied: next iteration)
         if (par_any < 0) flag_at(it) = 1;
+        return false;
     };
 
     // Register-lean check phase (LEAN): one check row at a time, its edges in chunks of six; the u
@@ -1117,20 +1149,23 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (it > 0) LDPC_SYNC();  // u of the exchanged blocks and the parity vote are visible (iteration 0: barrier below)
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
-            if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
-            else if (it == maxiters) { done = true; }
+            if constexpr (!WAVE_VERDICT) {
+                if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
+            }
+            if (!done && it == maxiters) { done = true; }
         }
         if constexpr (G == 1) { if (done) break; }
         else { if (__all(done)) break; }
 
         if (G == 1 || !done) variable_phase();
         LDPC_SYNC();
-        if (it > 0 && t == 0) flag_at(it - 1) = 0;
+        if constexpr (!WAVE_VERDICT) { if (it > 0 && t == 0) flag_at(it - 1) = 0; }
         if (G == 1 || !done) {
             if constexpr (LEAN == 2) check_phase_inplace(it);
             else if constexpr (LEAN == 1) check_phase_lean(it);
-            else check_phase(it, CAP_);
+            else if (check_phase(it, CAP_)) { done = true; ok = true; iters = it; }      // (wave verdict, decoder.rs:453-463)
         }
+        if constexpr (WAVE_VERDICT && G == 1) { if (done) break; }
     }
     };
     LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
@@ -1201,12 +1236,13 @@ constexpr int min_waves_per_simd()
     if (LEAN == 1) return 4;
     if (CODE == TM2048 && IPT == 1) return LDPC_TM2048_WAVES;
     if (CODE == TM1280 && IPT == 1) return 3;         // 183 -> 168 VGPRs: f32 28.4 -> 38.6, i8 27.0 -> 34.4 M codewords/s
-    // TC codes (one-wave workgroups, occupancy set by registers alone): 139-144 -> 128 VGPRs, four waves per SIMD
-    // instead of three: TC128 f32 507 -> 561, i8 478 -> 534; TC256 365 -> 391 / 349 -> 357; TC512 i8 249 -> 259 M
-    // codewords/s at 3 dB (five or six waves spill 60-100 registers and run 3-6x slower).  Not TC256 / TC512 i8 and
-    // i16: the 10-24 registers they spill at 128 sit in the prologue and epilogue, which at 5 dB (2 iterations) is most
-    // of a decode: TC256 i8 791 -> 636, TC512 i8 451 -> 434 M codewords/s there, for +2 % / +6 % at 3 dB.
-    if (CODE <= TC512 && IPT == 1 && !(CODE >= TC256 && sizeof(T) < 4)) return 4;
+    // TC codes (one-wave workgroups, occupancy set by registers alone): at 139-149 VGPRs three waves per SIMD.  Capping
+    // them at 128 for four waves paid before the wave verdict existed (TC128 f32 507 -> 561, TC256 365 -> 391 M
+    // codewords/s at 3 dB); the verdict's early exit costs 9-13 registers, which at 128 spill inside the loop
+    // (TC512 f32 273 -> 180), while at three waves it is a net gain everywhere but TC128 at 3 dB (-4 %):
+    //   f32, 3 dB / 5 dB, against four waves without verdict: TC128 534 / 1867 (556 / 1702), TC256 400 / 926 (394 / 783),
+    //   TC512 277 / 543 (273 / 485); i8: TC128 502 / 1798 (522 / 1561), TC256 383 / 948 (351 / 789), TC512 285 / 561 (255 / 462).
+    if (CODE <= TC512 && IPT == 1) return LDPC_WAVE_VERDICT ? 1 : (!(CODE >= TC256 && sizeof(T) < 4) ? 4 : 1);
     return 1;
 }
 
