@@ -909,7 +909,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
         });
         __builtin_amdgcn_sched_barrier(0);    // keep the requests ahead of the local-edge work
-        if constexpr (WAVE_VERDICT) {
+        if constexpr (WAVE_VERDICT) {     // (evaluating it after the local edges instead, which would cover the LDS latency, measures the same)
             int pe = 0;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value;
