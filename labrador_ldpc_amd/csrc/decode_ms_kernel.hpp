@@ -877,9 +877,18 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // they do the rest of the check phase -- the updates, minima and messages of an iteration whose result nobody
     // reads -- is skipped.  A success that takes k iterations then costs k + 0.35 passes instead of k + 1: +10-20 % at
     // 5 dB (2 iterations), +1-12 % at 3 dB (min_waves_per_simd() has the table); config 2 (TC512 f32 at 2 dB, 15
-    // iterations, 29 % failures) 108 -> 105.5.  Multi-wave codewords would need one more barrier per iteration for
-    // this, which costs more than the last half pass.
+    // iterations, 29 % failures) 109.5 -> 106.9.  Multi-wave codewords need one more barrier per iteration for this:
+    // WG_VERDICT below.
     constexpr bool WAVE_VERDICT = LDPC_WAVE_VERDICT && GEO::WG == 64 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
+    // The same for codewords of several waves needs a third barrier per iteration (parity -> flag -> barrier -> read).
+    // Where several workgroups share a CU the barrier hides behind the others and the skipped half pass is a net gain:
+    // TM1536 f32 59.0 -> 62.5 (3 dB; 31.6 -> 31.9 at 2 dB where most frames fail), i8 55.5 -> 57.6; TM1280 f32 67.8 ->
+    // 70.3 (its i8 / i16 kernels spill 23 registers with it: 65.2 -> 58.7).  Not where a workgroup fills a CU or the
+    // iteration count is high: TM2048 -1 % (2.5 dB) / -5 % (config 3), TM6144 -2.4 %; the lean TM5120 kernel would
+    // have to read its 39 marginals twice.
+    constexpr int WG_VERDICT_SET = LDPC_WG_VERDICT >= 0 ? LDPC_WG_VERDICT
+                                 : ((CODE == TM1536 && sizeof(T) <= 2) || ((CODE == TM1536 || CODE == TM1280) && std::is_same_v<T, float>)) ? 1 : 0;
+    constexpr bool WG_VERDICT = WG_VERDICT_SET != 0 && !WAVE_VERDICT && G == 1 && IPT == 1 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
     auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE -> bool {
         constexpr bool CAP = decltype(CAP_)::value != 0;
         // decoder.rs:414-450, and :391-405 of the NEXT iteration
@@ -930,6 +939,27 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             constexpr unsigned long long GROUP = NT >= 64 ? ~0ull : ((1ull << (NT & 63)) - 1ull);
             if (((odd >> (grp * NT)) & GROUP) == 0) return true;                        // :453
         }
+        if constexpr (WG_VERDICT) {
+            int pe = 0;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value;
+                static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
+                    constexpr int Rw = decltype(R_)::value;
+                    constexpr int D = row_degree(P, Rw);
+                    int xw[D];
+                    static_for<0, D>([&](auto J_) LDPC_INLINE {
+                        constexpr int J = decltype(J_)::value;
+                        constexpr int B = row_block(P, Rw, J);
+                        if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);
+                        else xw[J] = O::bits(va[S][P.blk[B].col]);
+                    });
+                    pe |= xor_reduce<D>(xw);
+                });
+            });
+            if (__ballot(pe < 0) != 0 && (tid & 63) == 0) flag_at(it) = 1;
+            LDPC_SYNC();
+            if (flag_at(it) == 0) return true;
+        }
         // bounded mode = the clamp-free copy of the loop: its codewords passed the LLR range vote
         constexpr int BND = (!CAP && NOCAP_POSSIBLE && LOCAL_IN_VAR == 0) ? 1 : 0;
         check_local(IC<BND>{});                                                        // (2)
@@ -962,7 +992,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
-                const int sgn = xor_reduce<D>(sr), par = WAVE_VERDICT ? 0 : xor_reduce<D>(xw);
+                const int sgn = xor_reduce<D>(sr), par = (WAVE_VERDICT || WG_VERDICT) ? 0 : xor_reduce<D>(xw);
 #ifdef LDPC_DIAG_NOMIN
                 static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = O::mag(a[decltype(J_)::value]); });
 #else
@@ -982,7 +1012,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 par_any |= par;
             });
         });
-        if constexpr (WAVE_VERDICT) return false;       // (some check of this codeword is unsatisfied: next iteration)
+        if constexpr (WAVE_VERDICT || WG_VERDICT) return false;       // (some check of this codeword is unsatisfied: next iteration)
         if (par_any < 0) flag_at(it) = 1;
         return false;
     };
@@ -1149,7 +1179,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (it > 0) LDPC_SYNC();  // u of the exchanged blocks and the parity vote are visible (iteration 0: barrier below)
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
-            if constexpr (!WAVE_VERDICT) {
+            if constexpr (!WAVE_VERDICT && !WG_VERDICT) {
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
             }
             if (!done && it == maxiters) { done = true; }
@@ -1165,7 +1195,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             else if constexpr (LEAN == 1) check_phase_lean(it);
             else if (check_phase(it, CAP_)) { done = true; ok = true; iters = it; }      // (wave verdict, decoder.rs:453-463)
         }
-        if constexpr (WAVE_VERDICT && G == 1) { if (done) break; }
+        if constexpr ((WAVE_VERDICT || WG_VERDICT) && G == 1) { if (done) break; }
     }
     };
     LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
