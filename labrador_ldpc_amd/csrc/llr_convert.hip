@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(256) hard_to_llrs_kernel(const uint8_t *__rest
 #pragma unroll
                 for (int j = 0; j < K; ++j) p.v[j] = ((field[u] >> (K - 1 - j)) & 1u) ? (T)-1 : (T)1;      // decoder.rs:489-491
 #if LLRC_NT_STORE
-                __builtin_nontemporal_store(*reinterpret_cast<const __attribute__((ext_vector_type(4))) int *>(&p),
-                                            reinterpret_cast<__attribute__((ext_vector_type(4))) int *>(llrs + i * K));
+                __attribute__((ext_vector_type(4))) int raw;
+                __builtin_memcpy(&raw, &p, 16);
+                __builtin_nontemporal_store(raw, reinterpret_cast<__attribute__((ext_vector_type(4))) int *>(llrs + i * K));
 #else
                 *reinterpret_cast<Piece<T> *>(llrs + i * K) = p;
 #endif
@@ -119,7 +120,8 @@ __global__ void __launch_bounds__(256) llrs_to_hard_kernel(const T *__restrict__
         for (int u = 0; u < UNROLL; ++u) {
             const size_t i = i0 + u * stride;
             if (i < pieces) {
-                const Piece<T> p = *reinterpret_cast<const Piece<T> *>(&raw[u]);
+                Piece<T> p;
+                __builtin_memcpy(&p, &raw[u], 16);
                 unsigned f = 0;
 #pragma unroll
                 for (int j = 0; j < K; ++j) f |= (p.v[j] < (T)0 ? 1u : 0u) << (K - 1 - j);                 // decoder.rs:504-506
