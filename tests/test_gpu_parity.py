@@ -99,12 +99,22 @@ def test_f32_corner_values(code):
     _compare(code, llrs, 20)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TM2048, LDPCCode.TM8192], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TC256, LDPCCode.TC512, LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048,
+                                  LDPCCode.TM5120, LDPCCode.TM8192], ids=lambda c: c.name)
 @pytest.mark.parametrize("maxiters", [0, 1, 2, 3])
 def test_small_maxiters(code, maxiters):
+    """Iteration caps around the early verdicts (the TC codes' in-wave verdict, TM1280 / TM1536's in-phase one): frames that
+    are codewords already (iters 0), that converge at the cap, one short of it, or not at all."""
     rng = np.random.default_rng(5)
     llrs, _ = oracle.awgn_llrs(code, rng, 64, 4.0, np.float32)
-    _compare(code, llrs, maxiters)
+    clean, _ = oracle.awgn_llrs(code, rng, 8, 30.0, np.float32)                # error-free: success at iteration 0
+    it, ok = _compare(code, np.concatenate([llrs, clean]), maxiters)
+    if maxiters >= 1 and code.punctured_bits() == 0:
+        assert (ok[-8:] == 1).all() and (it[-8:] == 0).all()
+    if maxiters >= 2:
+        assert (ok[-8:] == 1).all() and (it[-8:] <= 1).all()                  # punctured codes need one iteration (decoder.rs:607-645)
+    l8, _ = oracle.awgn_llrs(code, rng, 32, 5.0, np.int8)
+    _compare(code, l8, maxiters)
 
 
 def test_ragged_batches():
