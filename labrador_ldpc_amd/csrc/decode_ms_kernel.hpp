@@ -511,6 +511,23 @@ constexpr int selfcorr_carry_default()
     return (CODE == TM1280 || CODE == TM1536 || CODE == TM5120) ? 2 : 0;
 }
 
+// Kernels that run iteration 0 as a pass of its own (PEEL_FIRST in the kernel body).  Same-process A/B, M codewords/s:
+//   TC128 f32 1863 -> 2067, i8 1806 -> 2061; TC256 894 -> 1025 / 946 -> 1095; TC512 539 -> 598 / 555 -> 676 (5 dB);
+//   +3-7 % at 3 dB; config 2 (TC512 f32, 2 dB) 104.8 -> 109.2;
+//   TM2048 f32 43.1 -> 44.8, i8 42.6 -> 44.7, config 3 (2 dB) 34.6 -> 35.7; TM1536 f32 62.6 -> 62.9, i8 57.7 -> 59.2;
+//   TM6144 i8 10.79 -> 11.10; TM1280 i8 65.1 -> 68.1 -- but TM1280 f32 70.3 -> 63.5 (23 spilled registers at its 168).
+// The pair kernel lost with it (7.42 -> 6.94, round 1), the lean kernel's row loop has no such pass.
+template <int CODE, class T, int IPT>
+constexpr bool peel_first_default()
+{
+    constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
+    if (CODE <= TC512) return !std::is_same_v<T, double> || CODE == TC512;      // (f64: TC128 703 -> 483, TC256 384 -> 267, TC512 206 -> 250)
+    if (IPT != 1) return false;
+    if (CODE == TM2048 || CODE == TM1536) return narrow || std::is_same_v<T, float>;
+    if (CODE == TM6144 || CODE == TM1280) return narrow;
+    return false;
+}
+
 // ---- kernel geometry -----------------------------------------------------------------------
 template <int CODE, class T, int IPT>
 struct Geometry {
@@ -725,6 +742,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
     };
 
+    // Iteration 0 as a pass of its own (see check_phase): per kernel, peel_first_default()
+    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN == 0 &&
+                                (LDPC_LOCAL_IN_VAR >= 0 ? LDPC_LOCAL_IN_VAR : local_in_var_default<CODE, T, IPT, LEAN>()) == 0;
+    constexpr bool ZERO_FREE = PEEL_FIRST;
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
         if constexpr (PF) {
             if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -741,7 +762,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 v[S][B] = O::zero();
                 vneg = 0; vnz = 0;
                 constexpr int slot = exch_slot(P, B);
-                if constexpr (slot >= 0) {
+                if constexpr (slot >= 0 && !ZERO_FREE) {       // (a peeled first iteration never reads the slots)
                     constexpr int off = INPLACE ? 0 : lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                     lds_store(off + wire(B_, S_, tb), O::store(O::zero()));
                 }
@@ -808,7 +829,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
 
     // One iteration of message passing for this thread's indices: the two phases below.
-    auto variable_phase = [&]() LDPC_INLINE {
+    // FIRST_: iteration 0 of a codeword, peeled by kernels with PEEL_FIRST -- every u is zero, so the marginals are the
+    // LLRs and nothing is read from LDS
+    auto variable_phase = [&](auto FIRST_) LDPC_INLINE {
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;
         // marginals (decoder.rs:382-383, :408)
         int tv = t;
         if constexpr (INPLACE) asm volatile("" : "+v"(tv));     // keep the (large-offset) LDS addresses out of loop-carried VGPRs
@@ -848,6 +872,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     constexpr int cs = col_slot(P, C);
                     if constexpr (cs >= 0) *reinterpret_cast<int *>(gbase + hi_off(cs) + i * 4) = O::bits(acc);
                 } else {
+                if constexpr (!FIRST)
                 static_for<0, NB>([&](auto B_) LDPC_INLINE {
                     constexpr int B = decltype(B_)::value;
                     if constexpr (P.blk[B].col == C) {
@@ -889,8 +914,13 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr int WG_VERDICT_SET = LDPC_WG_VERDICT >= 0 ? LDPC_WG_VERDICT
                                  : ((CODE == TM1536 && sizeof(T) <= 2) || ((CODE == TM1536 || CODE == TM1280) && std::is_same_v<T, float>)) ? 1 : 0;
     constexpr bool WG_VERDICT = WG_VERDICT_SET != 0 && !WAVE_VERDICT && G == 1 && IPT == 1 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
-    auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE -> bool {
+    // Iteration 0 peeled (PEEL_FIRST; at high SNR a decode is two or three passes, and the first one is cheaper than
+    // the rest): u = 0 and v = 0 make every new v the marginal itself (decoder.rs:421-425
+    // with u == 0 and v == 0: x - 0, kept), so the pass needs no LDS reads in its variable phase and no
+    // subtract / test / select per edge in its check phase, and the exchange slots need no zeroing.
+    auto check_phase = [&](uint32_t it, auto CAP_, auto FIRST_) LDPC_INLINE -> bool {
         constexpr bool CAP = decltype(CAP_)::value != 0;
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;
         // decoder.rs:414-450, and :391-405 of the NEXT iteration
         int par_any = 0;          // bit 31 set if any owned check has odd parity
         // LDS addresses of the exchanged edges are two VALU ops each from `tb`; making `tb`
@@ -962,6 +992,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
         // bounded mode = the clamp-free copy of the loop: its codewords passed the LLR range vote
         constexpr int BND = (!CAP && NOCAP_POSSIBLE && LOCAL_IN_VAR == 0) ? 1 : 0;
+        if constexpr (FIRST) {
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {                              // (2) + (3) with u == 0, v == 0
+                static_for<0, NB>([&](auto B_) LDPC_INLINE {
+                    constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
+                    if constexpr (exch_slot(P, B) >= 0) v[S][B] = xs[S][B];
+                    else v[S][B] = va[S][P.blk[B].col];
+                });
+            });
+        } else {
         check_local(IC<BND>{});                                                        // (2)
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3)
@@ -970,6 +1009,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], u[S][B], IC<BND>{});
             });
         });
+        }
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (4)
             constexpr int S = decltype(S_)::value;
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
@@ -1175,7 +1215,18 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     uint32_t iters = maxiters;
     // the iterations; one copy of the loop per clamp mode (two check phases inside one loop spill)
     auto iterate = [&](auto CAP_) LDPC_INLINE {
-    for (uint32_t it = 0;; ++it) {
+    uint32_t it0 = 0;
+    if constexpr (PEEL_FIRST) {
+        if (maxiters == 0) done = true;
+        if constexpr (G == 1) { if (done) return; }
+        else { if (__all(done)) return; }
+        if (G == 1 || !done) variable_phase(IC<1>{});
+        LDPC_SYNC();
+        if (G == 1 || !done) { if (check_phase(0u, CAP_, IC<1>{})) { done = true; ok = true; iters = 0; } }
+        if constexpr (G == 1) { if (done) return; }
+        it0 = 1;
+    }
+    for (uint32_t it = it0;; ++it) {
         if (it > 0) LDPC_SYNC();  // u of the exchanged blocks and the parity vote are visible (iteration 0: barrier below)
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
@@ -1187,13 +1238,13 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if constexpr (G == 1) { if (done) break; }
         else { if (__all(done)) break; }
 
-        if (G == 1 || !done) variable_phase();
+        if (G == 1 || !done) variable_phase(IC<0>{});
         LDPC_SYNC();
         if constexpr (!WAVE_VERDICT) { if (it > 0 && t == 0) flag_at(it - 1) = 0; }
         if (G == 1 || !done) {
             if constexpr (LEAN == 2) check_phase_inplace(it);
             else if constexpr (LEAN == 1) check_phase_lean(it);
-            else if (check_phase(it, CAP_)) { done = true; ok = true; iters = it; }      // (wave verdict, decoder.rs:453-463)
+            else if (check_phase(it, CAP_, IC<0>{})) { done = true; ok = true; iters = it; }      // (wave verdict, decoder.rs:453-463)
         }
         if constexpr ((WAVE_VERDICT || WG_VERDICT) && G == 1) { if (done) break; }
     }
