@@ -516,14 +516,14 @@ constexpr int selfcorr_carry_default()
 //   +3-7 % at 3 dB; config 2 (TC512 f32, 2 dB) 104.8 -> 109.2;
 //   TM2048 f32 43.1 -> 44.8, i8 42.6 -> 44.7, config 3 (2 dB) 34.6 -> 35.7; TM1536 f32 62.6 -> 62.9, i8 57.7 -> 59.2;
 //   TM6144 i8 10.79 -> 11.10; TM1280 i8 65.1 -> 68.1 -- but TM1280 f32 70.3 -> 63.5 (23 spilled registers at its 168).
-// The pair kernel lost with it (7.42 -> 6.94, round 1), the lean kernel's row loop has no such pass.
+// The pair kernel lost with it (7.42 -> 6.94, round 1).
 template <int CODE, class T, int IPT>
 constexpr bool peel_first_default()
 {
     constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
     if (CODE <= TC512) return !std::is_same_v<T, double> || CODE == TC512;      // (f64: TC128 703 -> 483, TC256 384 -> 267, TC512 206 -> 250)
     if (IPT != 1) return false;
-    if (CODE == TM2048 || CODE == TM1536) return narrow || std::is_same_v<T, float>;
+    if (CODE == TM2048 || CODE == TM1536 || CODE == TM5120) return narrow || std::is_same_v<T, float>;    // (TM5120 = the lean kernel: i8 17.9 -> 18.4 at 4 dB)
     if (CODE == TM6144 || CODE == TM1280) return narrow;
     return false;
 }
@@ -743,7 +743,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
 
     // Iteration 0 as a pass of its own (see check_phase): per kernel, peel_first_default()
-    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN == 0 &&
+    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN != 2 &&
                                 (LDPC_LOCAL_IN_VAR >= 0 ? LDPC_LOCAL_IN_VAR : local_in_var_default<CODE, T, IPT, LEAN>()) == 0;
     constexpr bool ZERO_FREE = PEEL_FIRST;
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
@@ -1060,7 +1060,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // Register-lean check phase (LEAN): one check row at a time, its edges in chunks of six; the u
     // of an exchanged edge is read back from the LDS slot it was stored to, nothing per edge but v
     // (and the u of local edges) stays live between chunks; addresses are recomputed for the store.
-    auto check_phase_lean = [&](uint32_t it) LDPC_INLINE {
+    auto check_phase_lean = [&](uint32_t it, auto FIRST_) LDPC_INLINE {
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;      // iteration 0 peeled: u == 0, v == 0 (see check_phase)
         int par_any = 0;
         int tb = t * SZ;
         asm volatile("" : "+v"(tb));
@@ -1091,16 +1092,17 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                             constexpr int offu = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                             const int adr = wire(IC<B>{}, S_, tb);
                             xr[J - J0] = O::from_lds(lds_load(offx + adr));
-                            ur[J - J0] = O::from_lds(lds_load(offu + adr));
+                            if constexpr (!FIRST) ur[J - J0] = O::from_lds(lds_load(offu + adr));
                         } else {
                             xr[J - J0] = va[S][P.blk[B].col];
-                            ur[J - J0] = u[S][B];
+                            if constexpr (!FIRST) ur[J - J0] = u[S][B];
                         }
                     });
                     static_for<J0, J1>([&](auto J_) LDPC_INLINE {
                         constexpr int J = decltype(J_)::value;
                         constexpr int B = row_block(P, Rw, J);
-                        edge_update(S_, IC<B>{}, xr[J - J0], ur[J - J0], IC<0>{});     // :421-425
+                        if constexpr (FIRST) v[S][B] = xr[J - J0];
+                        else edge_update(S_, IC<B>{}, xr[J - J0], ur[J - J0], IC<0>{});     // :421-425
                         par ^= O::bits(xr[J - J0]);                                    // :445-447
                         sgn ^= O::bits(v[S][B]) & (int)0x80000000;                     // :439-441
                     });
@@ -1222,7 +1224,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         else { if (__all(done)) return; }
         if (G == 1 || !done) variable_phase(IC<1>{});
         LDPC_SYNC();
-        if (G == 1 || !done) { if (check_phase(0u, CAP_, IC<1>{})) { done = true; ok = true; iters = 0; } }
+        if (G == 1 || !done) {
+            if constexpr (LEAN == 1) check_phase_lean(0u, IC<1>{});
+            else if (check_phase(0u, CAP_, IC<1>{})) { done = true; ok = true; iters = 0; }
+        }
         if constexpr (G == 1) { if (done) return; }
         it0 = 1;
     }
@@ -1243,7 +1248,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if constexpr (!WAVE_VERDICT) { if (it > 0 && t == 0) flag_at(it - 1) = 0; }
         if (G == 1 || !done) {
             if constexpr (LEAN == 2) check_phase_inplace(it);
-            else if constexpr (LEAN == 1) check_phase_lean(it);
+            else if constexpr (LEAN == 1) check_phase_lean(it, IC<0>{});
             else if (check_phase(it, CAP_, IC<0>{})) { done = true; ok = true; iters = it; }      // (wave verdict, decoder.rs:453-463)
         }
         if constexpr ((WAVE_VERDICT || WG_VERDICT) && G == 1) { if (done) break; }
