@@ -516,7 +516,7 @@ constexpr int selfcorr_carry_default()
 //   +3-7 % at 3 dB; config 2 (TC512 f32, 2 dB) 104.8 -> 109.2;
 //   TM2048 f32 43.1 -> 44.8, i8 42.6 -> 44.7, config 3 (2 dB) 34.6 -> 35.7; TM1536 f32 62.6 -> 62.9, i8 57.7 -> 59.2;
 //   TM6144 i8 10.79 -> 11.10; TM1280 i8 65.1 -> 68.1 -- but TM1280 f32 70.3 -> 63.5 (23 spilled registers at its 168).
-// The pair kernel lost with it (7.42 -> 6.94, round 1).
+// The pair kernel has its own switch (LDPC_PAIR_PEEL_FIRST: TM8192 f32 7.51 -> 7.70).
 template <int CODE, class T, int IPT>
 constexpr bool peel_first_default()
 {

@@ -143,6 +143,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             static_for<0, NTX>([&](auto C_) LDPC_INLINE { llr[S][decltype(C_)::value] = O::load(lraw[S][decltype(C_)::value]); });
         });
 #ifndef LDPC_DIAG_NOZERO
+        if constexpr (!LDPC_PAIR_PEEL_FIRST)
         static_for<0, NX>([&](auto X_) LDPC_INLINE {                                   // u = 0 in every exchange slot
             lds2(lds_xu_off(P, decltype(X_)::value, BLK_BYTES) + tb8) = ldpc_f2{0.0f, 0.0f};
         });
@@ -180,7 +181,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
-    auto variable_phase = [&](auto BND_) LDPC_INLINE {
+    // FIRST_: iteration 0 peeled (LDPC_PAIR_PEEL_FIRST): u == 0 and v == 0, see decode_ms_kernel.hpp PEEL_FIRST
+    auto variable_phase = [&](auto BND_, auto FIRST_) LDPC_INLINE {
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
@@ -190,6 +193,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             if constexpr (C == NCOLS / 2) LDPC_SETPRIO(0);
             R acc0 = O::zero(), acc1 = O::zero();
             if constexpr (C < NTX) { acc0 = llr[0][C]; acc1 = llr[1][C]; }
+            if constexpr (!FIRST)
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int B = decltype(B_)::value;
                 if constexpr (P.blk[B].col == C) {
@@ -214,14 +218,18 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col], BND_);
+                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) < LOCAL_IN_VAR) {
+                    if constexpr (FIRST) v[S][B] = va[S][P.blk[B].col];
+                    else edge_update(S_, B_, va[S][P.blk[B].col], BND_);
+                }
             });
         });
     };
 
     // ---- check phase (decoder.rs:414-450 and :391-405 of the next iteration) -------------------------
-    auto check_phase = [&](uint32_t it, auto CAP_) LDPC_INLINE {
+    auto check_phase = [&](uint32_t it, auto CAP_, auto FIRST_) LDPC_INLINE {
         constexpr bool CAP = decltype(CAP_)::value != 0;
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;
         constexpr int BND = (!CAP && NOCAP_POSSIBLE) ? 1 : 0;
         int par_any = 0;
         int tq = t;
@@ -262,14 +270,20 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2) local edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) >= LOCAL_IN_VAR) edge_update(S_, B_, va[S][P.blk[B].col], IC<BND>{});
+                if constexpr (exch_slot(P, B) < 0 && pair_local_rank(P, S, B) >= LOCAL_IN_VAR) {
+                    if constexpr (FIRST) v[S][B] = va[S][P.blk[B].col];
+                    else edge_update(S_, B_, va[S][P.blk[B].col], IC<BND>{});
+                }
             });
         });
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
-                if constexpr (exch_slot(P, B) >= 0) edge_update(S_, B_, xs[S][B], IC<BND>{});
+                if constexpr (exch_slot(P, B) >= 0) {
+                    if constexpr (FIRST) v[S][B] = xs[S][B];
+                    else edge_update(S_, B_, xs[S][B], IC<BND>{});
+                }
             });
         });
         static_for<0, NROWS>([&](auto R_) LDPC_INLINE {                                // (4) per check row, both indices
@@ -346,7 +360,15 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #endif
         // the iterations, as one loop per clamp mode (two check phases inside ONE loop cost 330 spilled VGPRs)
         auto iterate = [&](auto CAP_) LDPC_INLINE {
-            for (uint32_t it = 0;; ++it) {
+            uint32_t it0 = 0;
+            if constexpr (LDPC_PAIR_PEEL_FIRST != 0) {
+                if (maxiters == 0) { done = true; return; }
+                variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{}, IC<1>{});
+                LDPC_SYNC();
+                check_phase(0u, CAP_, IC<1>{});
+                it0 = 1;
+            }
+            for (uint32_t it = it0;; ++it) {
                 if (it > 0) LDPC_SYNC();          // (the barrier before iteration 0 is taken below, before the clamp mode is read)
 #ifdef LDPC_DIAG_STAMPS
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -355,7 +377,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
                 else if (it == maxiters) { done = true; }
                 if (done) break;
-                variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{});
+                variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{}, IC<0>{});
 #ifdef LDPC_DIAG_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -365,7 +387,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
                 if (it > 0 && t == 0) flag_at(it - 1) = 0;
-                check_phase(it, CAP_);
+                check_phase(it, CAP_, IC<0>{});
 #ifdef LDPC_DIAG_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 t3 = __builtin_amdgcn_s_memtime();
