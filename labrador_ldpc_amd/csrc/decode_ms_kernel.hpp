@@ -523,8 +523,8 @@ constexpr bool peel_first_default()
     constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
     if (CODE <= TC512) return !std::is_same_v<T, double> || CODE == TC512;      // (f64: TC128 703 -> 483, TC256 384 -> 267, TC512 206 -> 250)
     if (IPT != 1) return false;
-    if (CODE == TM2048 || CODE == TM1536 || CODE == TM5120) return narrow || std::is_same_v<T, float>;    // (TM5120 = the lean kernel: i8 17.9 -> 18.4 at 4 dB)
-    if (CODE == TM6144 || CODE == TM1280) return narrow;
+    if (CODE == TM2048 || CODE == TM1536 || CODE == TM5120 || CODE == TM6144) return narrow || std::is_same_v<T, float>;    // (TM5120 = the lean kernel: i8 17.9 -> 18.4 at 4 dB; TM6144 f32 10.69 -> 11.42)
+    if (CODE == TM1280) return narrow;
     return false;
 }
 
@@ -743,8 +743,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
 
     // Iteration 0 as a pass of its own (see check_phase): per kernel, peel_first_default()
-    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN != 2 &&
-                                (LDPC_LOCAL_IN_VAR >= 0 ? LDPC_LOCAL_IN_VAR : local_in_var_default<CODE, T, IPT, LEAN>()) == 0;
+    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN != 2;
     constexpr bool ZERO_FREE = PEEL_FIRST;
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
         if constexpr (PF) {
@@ -893,7 +892,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 }
             });
         });
-        if constexpr (LEAN == 0) local_edges(IC<1>{}, IC<0>{});      // (kernels that move local edges here have no bounded mode)
+        if constexpr (LEAN == 0 && !FIRST) local_edges(IC<1>{}, IC<0>{});      // (kernels that move local edges here have no bounded mode; a peeled first pass sets every v in its check phase)
     };
 
     // Codewords that live inside ONE wave (the TC codes: 16 / 32 / 64 threads each) get their verdict without a
