@@ -35,7 +35,13 @@ for i, (addr, text, tgt) in enumerate(body):
             if sum(1 for t in span if t.startswith("s_barrier")) == 2:
                 loops.append(span)
 loops.sort(key=lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), -sum(1 for t in sp if t.startswith("v_mul_f32")), len(sp)))
-loop = loops[0]
+# among the clamp-free copies (as many v_min_f32 / v_mul_f32 as the first) take the one with the LARGEST VALU count: since
+# iteration 0 is peeled the compiler rotates some copies of the loop, and a backward branch can then span a body that
+# lacks the rotated part
+key = lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), sum(1 for t in sp if t.startswith("v_mul_f32")))
+same = [sp for sp in loops if key(sp) == key(loops[0])]
+quarter = collections.Counter(sum(1 for t in sp if t.startswith("ds_")) for sp in same).most_common(1)[0][0]
+loop = max((sp for sp in same if sum(1 for t in sp if t.startswith("ds_")) == quarter), key=lambda sp: sum(1 for t in sp if t.startswith("v_")))
 FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|fma|pk_|lshl_add|lshl_or|xad)")
 cls = collections.Counter()
 ops = collections.Counter()
