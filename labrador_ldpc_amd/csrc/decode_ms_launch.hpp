@@ -86,9 +86,11 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
                       size_t batch, uint32_t maxiters, hipStream_t stream)
 {
     // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
-    // is TM5120 only (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB).  Measured slower
+    // is TM5120 (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB) and the narrow types of TM1280.  Measured slower
     // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
-    constexpr int LEAN = CODE == TM5120 && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
+    // TM1280 i8 / i16: 168 -> 116 VGPRs, four waves per SIMD instead of three: 68.4 -> 71.0 (its f32 kernel 70.5 -> 69.5: not).
+    constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
+    constexpr int LEAN = (CODE == TM5120 || (CODE == TM1280 && narrow)) && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
     return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream);
 }
 
