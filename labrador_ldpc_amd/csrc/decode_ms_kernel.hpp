@@ -520,11 +520,11 @@ constexpr int selfcorr_carry_default()
 template <int CODE, class T, int IPT>
 constexpr bool peel_first_default()
 {
-    constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
     if (CODE <= TC512) return !std::is_same_v<T, double> || CODE == TC512;      // (f64: TC128 703 -> 483, TC256 384 -> 267, TC512 206 -> 250)
     if (IPT != 1) return false;
-    if (CODE == TM2048 || CODE == TM1536 || CODE == TM5120 || CODE == TM6144) return narrow || std::is_same_v<T, float>;    // (TM5120 = the lean kernel: i8 17.9 -> 18.4 at 4 dB; TM6144 f32 10.69 -> 11.42)
-    if (CODE == TM1280) return narrow;
+    // every type (i32 +2-6 %, f64 0-6 %); TM5120 = the lean kernel: i8 17.9 -> 18.4 at 4 dB; TM6144 f32 10.69 -> 11.42
+    if (CODE == TM2048 || CODE == TM1536 || CODE == TM5120 || CODE == TM6144) return true;
+    if (CODE == TM1280) return !std::is_same_v<T, float>;
     return false;
 }
 
