@@ -20,3 +20,23 @@ def test_decode_kernels_have_uniform_control_flow():
     bad = {k: v for k, v in table.items()
            if v[1] > 16 and "decode_ms_f64_kernel" not in k[1]}     # the f64 workspace fallback (variant 100) is a plain loop kernel
     assert not bad, f"kernels with EXEC-masked loops (mis-structured control flow): {bad}"
+
+
+def test_library_build_refuses_tuning_and_diagnostic_switches(tmp_path):
+    """Round 1's review: one stray -D in EXTRA must not ship a mistuned or broken decoder.  Every LDPC_* tuning
+    setting and LDPC_DIAG_* diagnostic is reserved to tools/kbench.hip (which defines LDPC_KBENCH): a library
+    translation unit that sets one stops at the #error of csrc/decode_ms_tuning.hpp."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "labrador_ldpc_amd", "csrc")
+    for switch in ("LDPC_DIAG_NOMIN", "LDPC_DIAG_FIXED_ITERS", "LDPC_PEEL_FIRST=0", "LDPC_WAVE_VERDICT=0", "LDPC_SELFCORR_CARRY=2",
+                   "LDPC_PAIR_PEEL_FIRST=0", "LDPC_NOCAP=0", "LDPC_PRIO=0"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++20", "-fsyntax-only", "-D" + switch, "-I" + csrc,
+                            "-x", "hip", os.path.join(csrc, "decode_ms_tuning.hpp")], capture_output=True, text=True)
+        assert r.returncode != 0 and "tools/kbench.hip only" in r.stderr, (switch, r.stderr[-300:])
+    ok = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++20", "-fsyntax-only", "-DLDPC_KBENCH", "-DLDPC_PEEL_FIRST=0", "-I" + csrc,
+                         "-x", "hip", os.path.join(csrc, "decode_ms_tuning.hpp")], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-300:]
