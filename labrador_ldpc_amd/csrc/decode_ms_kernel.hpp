@@ -907,11 +907,12 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // The same for codewords of several waves needs a third barrier per iteration (parity -> flag -> barrier -> read).
     // Where several workgroups share a CU the barrier hides behind the others and the skipped half pass is a net gain:
     // TM1536 f32 59.0 -> 62.5 (3 dB; 31.6 -> 31.9 at 2 dB where most frames fail), i8 55.5 -> 57.6; TM1280 f32 67.8 ->
-    // 70.3 (its i8 / i16 kernels spill 23 registers with it: 65.2 -> 58.7).  Not where a workgroup fills a CU or the
+    // 70.3 (its i8 / i16 kernels spill 23 registers with it: 65.2 -> 58.7; they run the lean kernel now); i32 +5-7 %, f64
+    // +1-5 % on both codes.  Not where a workgroup fills a CU or the
     // iteration count is high: TM2048 -1 % (2.5 dB) / -5 % (config 3), TM6144 -2.4 %; the lean TM5120 kernel would
     // have to read its 39 marginals twice.
     constexpr int WG_VERDICT_SET = LDPC_WG_VERDICT >= 0 ? LDPC_WG_VERDICT
-                                 : ((CODE == TM1536 && sizeof(T) <= 2) || ((CODE == TM1536 || CODE == TM1280) && std::is_same_v<T, float>)) ? 1 : 0;
+                                 : (CODE == TM1536 || (CODE == TM1280 && !(sizeof(T) <= 2))) ? 1 : 0;
     constexpr bool WG_VERDICT = WG_VERDICT_SET != 0 && !WAVE_VERDICT && G == 1 && IPT == 1 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
     // Iteration 0 peeled (PEEL_FIRST; at high SNR a decode is two or three passes, and the first one is cheaper than
     // the rest): u = 0 and v = 0 make every new v the marginal itself (decoder.rs:421-425
