@@ -345,13 +345,19 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #endif
     if (t == 0) cap_flag() = 0;
     LDPC_SYNC();
-    if (blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
+    // Where the next codeword's LLR loads are issued: before this one's epilogue (f32: 7.35 -> 7.66 M codewords/s, the
+    // epilogue covers part of their latency) or at the top of its own turn (i8 / i16: the early loads' raw bytes are
+    // spilled across the epilogue at the 128-register budget -- which also waits for them on the spot -- 48 spilled
+    // registers against 3, 6.99 -> 7.09).  LDPC_PAIR_FETCH_EARLY: -1 = per type, 0 / 1 = force.
+    constexpr bool FETCH_EARLY = LDPC_PAIR_FETCH_EARLY >= 0 ? LDPC_PAIR_FETCH_EARLY != 0 : sizeof(T) >= 4;
+    if (FETCH_EARLY && blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
 #ifdef LDPC_DIAG_STAMPS
     const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime(), loop_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
         cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-        (void)first;                              // (this codeword's LLR loads were issued behind the previous epilogue)
+        (void)first;                              // (FETCH_EARLY: this codeword's LLR loads were issued behind the previous epilogue)
+        if constexpr (!FETCH_EARLY) fetch_llrs(cw);
         begin_codeword();
         bool done = false, ok = false;
         uint32_t iters = maxiters;
@@ -409,7 +415,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         }
 #endif
         // the next codeword's LLR loads, issued before this one's epilogue (fixed cost per codeword 2.55 -> 2.12 us)
-        if (g + gridDim.x < n_groups) fetch_llrs((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
+        if (FETCH_EARLY && g + gridDim.x < n_groups) fetch_llrs((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
         // s_bitreplicate doubles every bit), then bit-reversed per byte
