@@ -3,9 +3,11 @@
 
 Metric (BASELINE.json): decoded codewords/sec @ 25 min-sum iterations, TM8192, Eb/N0 = 2 dB.
 A "step" is one pass of the hot path (one decode_ms kernel launch through the C ABI) over this rank's
-shard of synthetic AWGN frames, already resident in HBM.  Independent frames shard across GPUs with no
-collective (weak scaling: every GPU decodes --frames-per-gpu frames; at 8 GPUs the default is exactly
-BASELINE config 4, 4 194 304 frames).
+shard of synthetic AWGN frames, already resident in HBM.  The job is BASELINE config 4 -- 4 194 304 TM8192
+frames (--total-frames) -- whatever the number of GPUs: one GPU decodes all of it (137 GB of LLRs fit its
+288 GB), N GPUs a contiguous 1/N each with no collective ("scaling": "strong"; the reference's harness is
+the same shape: one job, however many workers, perftest/src/main.rs:39-52).  --frames-per-gpu F switches to
+F frames on every GPU instead ("weak").
 
 Launching:  `python bench.py --gpus N` starts the N ranks itself (one child process per GPU, created
 before anything in this process touches a GPU); under `python -m torch.distributed.run ... bench.py
@@ -16,10 +18,12 @@ torch is plumbing only: device memory, streams, events, the barrier.
 Prints ONE JSON line on rank 0 with, beyond the contract's fields,
   roofline     -- algorithmic HBM bytes per launch / kernel time (HIP events on the launch stream) vs 8 TB/s
   valu_issue   -- the limiter the kernel actually runs into
-  configs      -- N=1 only: BASELINE configs 2, 3 and 5 (both operating points), a few launches each
+  configs      -- N=1 only: BASELINE config 1 (one TC128 frame, CPU oracle beside the single-frame C entry), config 4's
+                  first and last 524 288-frame slice (what each of 8 GPUs gets), configs 2, 3 and 5 (both operating points)
   cpu_baseline -- N=1 only: the CPU oracle (C port of the reference; Rust cannot be built in this image),
                   built -march=native on this host, on fixed samples of the frames the GPU decoded:
                   1 core and all cores; the same frames are compared bit for bit (parity)
+  parity       -- every rank compares a fixed sample of its shard with the oracle; mismatches are summed over ranks
 and exits non-zero, with "value": null, if any compared frame differs.
 """
 import argparse
@@ -32,13 +36,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-VALU_PEAK_G = 256 * 4 * 2 / 4 * 2.4   # 256 CUs x 4 SIMDs x 2 wave-instructions per 4 cycles x 2.4 GHz = 1228.8 G/s
+VALU_PEAK_G = 256 * 4 * 2 / 4 * 2.4   # 256 CUs x 4 SIMDs x 2 wave-instructions per 4 cycles x 2.4 GHz (nominal) = 1228.8 G/s
+SHADER_CLOCK_UNDER_LOAD_GHZ = 2.30    # measured: s_memtime against the 100 MHz s_memrealtime inside the kernel (tools/kbench.hip stamps)
+SLICE_FRAMES = 524288                 # config 4 over 8 GPUs: what one GPU decodes
 
 # BASELINE.json configs beyond the headline one: (key, code, dtype, frames per GPU, Eb/N0 dB)
 EXTRA_CONFIGS = [
     ("config2_TC512_f32", "TC512", "f32", 65536, 2.0),
     ("config3_TM2048_f32", "TM2048", "f32", 1048576, 2.0),
-    ("config5_TM5120_i8_4dB", "TM5120", "i8", 524288, 4.0),      # per-GPU slice of 4 194 304 frames over 8 GPUs
+    ("config5_TM5120_i8_4dB", "TM5120", "i8", 524288, 4.0),      # per-GPU slice of 4 194 304 frames over 8 GPUs (all of them fit one GPU too: 20 GiB)
     ("config5_TM5120_i8_2dB", "TM5120", "i8", 524288, 2.0),      # nothing converges: fixed 25-iteration work
 ]
 
@@ -86,15 +92,18 @@ class Workload:
         self.succ = torch.empty((frames,), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
 
-    def step(self, maxiters, variant=0):
-        self.code.decode_ms_batch(self.llrs, maxiters, output=self.out, iters=self.iters, success=self.succ, variant=variant)
+    def step(self, maxiters, variant=0, frames=None):
+        lo, hi = frames or (0, self.frames)
+        self.code.decode_ms_batch(self.llrs[lo:hi], maxiters, output=self.out[lo:hi], iters=self.iters[lo:hi], success=self.succ[lo:hi],
+                                  variant=variant)
 
-    def timed(self, maxiters, steps, warmup, variant=0, barrier=lambda: None):
-        """(wall seconds of `steps` launches, mean kernel ms from HIP events on the launch stream)."""
+    def timed(self, maxiters, steps, warmup, variant=0, barrier=lambda: None, frames=None):
+        """(wall seconds of `steps` launches, mean kernel ms from HIP events on the launch stream); `frames` = (lo, hi):
+        only that slice of the batch."""
         import numpy as np
         import torch
         for _ in range(warmup):
-            self.step(maxiters, variant)
+            self.step(maxiters, variant, frames)
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         barrier()
@@ -102,7 +111,7 @@ class Workload:
         t0 = time.perf_counter()
         for a, b in ev:                     # decode_ms_batch launches on torch's current stream, where the events sit
             a.record()
-            self.step(maxiters, variant)
+            self.step(maxiters, variant, frames)
             b.record()
         torch.cuda.synchronize()
         barrier()
@@ -112,66 +121,130 @@ class Workload:
     def stats(self):
         return float(self.iters.double().mean()), 1.0 - float(self.succ.double().mean())
 
-    def compare(self, maxiters, sample, nthreads, lib=None):
-        """Decode the first `sample` frames on the CPU oracle; (seconds, threads, mismatching frames)."""
+    def compare(self, maxiters, sample, nthreads, lib=None, offset=0):
+        """Decode `sample` frames from `offset` on the CPU oracle; (seconds, threads, mismatching frames)."""
         import numpy as np
         import oracle
-        h = self.llrs[:sample].cpu().numpy()
+        sl = slice(offset, offset + sample)
+        h = self.llrs[sl].cpu().numpy()
         t1 = time.perf_counter()
         o_c, it_c, ok_c, used = oracle.decode_ms_batch(self.code, h, maxiters, nthreads, lib=lib)
         cpu_s = time.perf_counter() - t1
-        o_g = self.out[:sample].cpu().numpy()
-        it_g = self.iters[:sample].cpu().numpy().astype(np.int64)
-        ok_g = self.succ[:sample].cpu().numpy().astype(np.int64)
+        o_g = self.out[sl].cpu().numpy()
+        it_g = self.iters[sl].cpu().numpy().astype(np.int64)
+        ok_g = self.succ[sl].cpu().numpy().astype(np.int64)
         mism = int(((it_g != it_c.astype(np.int64)) | (ok_g != ok_c.astype(np.int64)) | (o_g != o_c).any(axis=1)).sum())
         return cpu_s, used, mism
 
 
 def kernel_name(code_name, dtype, variant):
-    return "decode_ms_pair_kernel" if (code_name == "TM8192" and variant in (0, 32)) else "decode_ms_kernel"
+    return "decode_ms_pair_kernel" if (code_name == "TM8192" and (variant & 255) in (0, 32)) else "decode_ms_kernel"
 
 
-def profile_counters(key):
-    """Per-launch PMC figures of the committed profile of this kernel (profiles/hbm_traffic.json), or None."""
+def library_build_id():
+    """sha256[:16] of the shared library this process loaded -- what ties a committed profile to the code that is timed."""
+    import hashlib
+    import labrador_ldpc_amd as la
+    with open(la.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def profile_counters(key, build_id, path=None):
+    """(per-launch PMC figures of the committed profile of this kernel, None) -- or (None, why not).  The figures count for a
+    bench line only if they were collected on THIS library build (profiles/hbm_traffic.json records the build it profiled);
+    a kernel edit that was not re-profiled must not leave a stale figure in a driver-stamped line."""
     try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            t = json.load(f).get(key)
-        return t if t and t.get("frames") else None
-    except Exception:
-        return None
+        with open(path or os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            doc = json.load(f)
+    except Exception as e:
+        return None, f"no profile: {e}"
+    t = doc.get(key)
+    if not t or not t.get("frames"):
+        return None, f"no profile of {key}"
+    have = t.get("library_build") or doc.get("library_build")
+    if have != build_id:
+        return None, f"stale profile: counters of {key} were collected on library build {have}, this run loaded {build_id}"
+    return t, None
 
 
-def roofline_of(code, code_name, dtype, variant, frames, kernel_ms):
+def limiter_text(code, itemsize, mean_iters):
+    visits = 2 * code.paritycheck_sum() * (mean_iters + 1)
+    return (f"VALU issue + LDS, not HBM: {algorithmic_bytes_per_codeword(code, itemsize)} B of I/O per "
+            f"{visits / 1e3:.0f} k edge visits ({code.paritycheck_sum()} edges x 2 passes x {mean_iters + 1:.1f} iterations); see valu_issue")
+
+
+def roofline_of(code, code_name, dtype, variant, frames, kernel_ms, mean_iters, build_id):
     itemsize = 4 if dtype == "f32" else 1
     bytes_per_launch = frames * algorithmic_bytes_per_codeword(code, itemsize)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    prof = profile_counters(f"{code_name}_{dtype}")
+    prof, why = profile_counters(f"{code_name}_{dtype}", build_id)
     traffic = prof["hbm_bytes_per_launch"] * (frames / prof["frames"]) if prof else None
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": kernel_name(code_name, dtype, variant), "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "limiter": "VALU issue + LDS, not HBM (34 KB of I/O per ~1.1 M edge visits): see valu_issue"}
+            "algorithmic_bytes_per_launch": bytes_per_launch, "limiter": limiter_text(code, itemsize, mean_iters)}
+    if prof:
+        roof["traffic_source"] = (f"PMC FETCH_SIZE x2 + WRITE_SIZE of a {prof['frames']}-frame launch of this library build "
+                                  f"({build_id}), scaled by frames (profiles/hbm_traffic.json)")
+    else:
+        roof["traffic_note"] = why
     valu = None
     if prof and prof.get("valu_insts_per_launch"):
         # wave-level VALU instructions (PMC SQ_INSTS_VALU of the profiled launch, scaled to this one) against the issue peak
         ach = prof["valu_insts_per_launch"] * (frames / prof["frames"]) / (kernel_ms * 1e-3) / 1e9
+        at_clock = VALU_PEAK_G * SHADER_CLOCK_UNDER_LOAD_GHZ / 2.4
         valu = {"achieved": ach, "peak": VALU_PEAK_G, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_G,
-                "source": "SQ_INSTS_VALU per frame from profiles/hbm_traffic.json (same code, Eb/N0 and iteration cap)"}
+                "peak_at_measured_clock": at_clock, "frac_at_measured_clock": ach / at_clock,
+                "derived": True,
+                "source": f"SQ_INSTS_VALU per frame of the profiled launch (same library build {build_id}, same code, Eb/N0 and "
+                          f"iteration cap) x this run's frames / kernel time; peak at the nominal 2.4 GHz and at the "
+                          f"{SHADER_CLOCK_UNDER_LOAD_GHZ} GHz the chip holds under this load"}
         if prof.get("avg_issue_cycles_per_instruction"):
             # the peak above is for 2-cycle instructions only; this kernel's mix (tools/valu_mix.py: static count over the
             # iteration loop, per-class issue cost from tools/ubench) averages more, so in VALU CYCLES the fraction is
             c = prof["avg_issue_cycles_per_instruction"]
-            valu["cycle_weighted"] = {"avg_issue_cycles_per_instruction": c, "frac_of_valu_cycles_at_2.4GHz": ach / VALU_PEAK_G * c / 2.0,
-                                      "note": "before the co-issue of F-class instructions with 4-cycle ones of other waves; "
-                                              "the chip holds 2.30 GHz under this load (s_memtime against s_memrealtime, tools/kbench.hip stamps), not 2.4"}
+            valu["cycle_weighted"] = {"avg_issue_cycles_per_instruction": c,
+                                      "frac_of_valu_cycles_at_2.4GHz": ach / VALU_PEAK_G * c / 2.0,
+                                      "frac_of_valu_cycles_at_measured_clock": ach / at_clock * c / 2.0,
+                                      "note": "before the co-issue of F-class instructions with 4-cycle ones of other waves"}
     return roof, valu
+
+
+def config1_leg(args):
+    """BASELINE config 1: TC128, ONE codeword, 50 iterations, AWGN at 3 dB -- the reference's own CPU-runnable shape
+    (capi/src/lib.rs:83-95: one frame, caller-owned buffers).  The CPU oracle and the single-frame C entry point of this
+    library decode the same frame; results must be equal; both latencies are reported."""
+    import numpy as np
+    import oracle
+    from labrador_ldpc_amd import LDPCCode
+    code = LDPCCode.TC128
+    rng = np.random.default_rng(0x1DBC + int(code))
+    llrs, _ = oracle.awgn_llrs(code, rng, 1, 3.0, np.float32)
+    frame = llrs[0]
+    ok_c, it_c, out_c = oracle.decode_ms(code, frame, 50)
+    out_g = np.zeros(code.output_len(), dtype=np.uint8)
+    ok_g, it_g = code.decode_ms(frame, out_g, maxiters=50)
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.decode_ms(code, frame, 50)
+    cpu_us = (time.perf_counter() - t0) / reps * 1e6
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        code.decode_ms(frame, out_g, maxiters=50)
+    gpu_us = (time.perf_counter() - t0) / reps * 1e6
+    equal = bool(ok_c == ok_g and it_c == it_g and (out_c == out_g).all())
+    return {"workload": "TC128 f32, 1 codeword, max_iters 50, AWGN Eb/N0 3.0 dB (the reference's single-frame call shape)",
+            "success": bool(ok_g), "iters": int(it_g), "equal_to_cpu_oracle": equal,
+            "cpu_oracle_us_per_call": cpu_us, "gpu_single_frame_entry_us_per_call": gpu_us,
+            "note": "latency of one call incl. the Python binding; the GPU figure is launch + two PCIe copies of one frame, "
+                    "not a throughput"}, (0 if equal else 1)
 
 
 def run_rank(args):
     import numpy as np
     import torch
     from labrador_ldpc_amd import LDPCCode
-    from labrador_ldpc_amd.sharding import init_ranks, reduce_max, barrier, finish_ranks
+    from labrador_ldpc_amd.sharding import init_ranks, reduce_max, reduce_sum, barrier, finish_ranks, shard_range
 
     rank, local_rank, world = init_ranks()
     if world != args.gpus:
@@ -190,38 +263,56 @@ def run_rank(args):
     dev = torch.device("cuda", ordinal)
 
     code = LDPCCode[args.code]
-    F = args.frames_per_gpu
+    if args.frames_per_gpu:
+        F, total, scaling = args.frames_per_gpu, args.frames_per_gpu * world, "weak"
+    else:
+        (_, F), total, scaling = shard_range(args.total_frames, world, rank), args.total_frames, "strong"
+    build_id = library_build_id()
     w = Workload(code, args.dtype, F, args.ebn0, args.pool, rank, dev)
     elapsed, kernel_ms = w.timed(args.maxiters, args.steps, args.warmup, args.variant, barrier)
     elapsed, kernel_ms_max = reduce_max([elapsed, kernel_ms])              # slowest rank
     mean_iters, frame_fail = w.stats()
 
+    # ---- every rank: a fixed sample of its own shard against the CPU oracle (N=1: the cpu_baseline samples below) ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    mism_rank, compared_rank = 0, 0
+    if world > 1 and not args.no_cpu:
+        import oracle                                  # test infrastructure: the checker
+        compared_rank = min(F, args.rank_parity_frames)
+        _, _, mism_rank = w.compare(args.maxiters, compared_rank, max(1, usable_cores() // world))
+    if world > 1:
+        mism_total, compared_total = (int(x) for x in reduce_sum([mism_rank, compared_rank]))
+
     result, failed = None, False
     if rank == 0:
         headline = args.code == "TM8192" and args.maxiters == 25 and args.ebn0 == 2.0 and args.dtype == "f32"
-        roof, valu = roofline_of(code, args.code, args.dtype, args.variant, F, kernel_ms_max)
-        value = world * F * args.steps / elapsed
+        roof, valu = roofline_of(code, args.code, args.dtype, args.variant, F, kernel_ms_max, mean_iters, build_id)
+        value = total * args.steps / elapsed
+        what = (f"{total} frames on {world} GPU{'s' if world > 1 else ''}" +
+                (" = BASELINE config 4 whole" if headline and total == 4194304 else "") +
+                (f" ({F} per GPU)" if world > 1 else ""))
         result = {
             "metric": "decoded codewords/sec @25 min-sum iters, TM8192, Eb/N0=2dB; 1/2/4/8 GPU" if headline else
                       f"decoded codewords/sec @{args.maxiters} min-sum iters, {args.code} {args.dtype}, Eb/N0={args.ebn0}dB",
             "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.code} {args.dtype} LLRs, {F} frames per GPU resident in HBM ({world * F} total"
-                                   + ("; BASELINE config 4 = 4194304 frames over 8 GPUs" if headline else "")
-                                   + f"), max_iters {args.maxiters} with early termination, AWGN Eb/N0 {args.ebn0} dB, "
-                                     f"{args.pool} random codewords",
-                       "code": args.code, "frames_per_gpu": F, "max_iters": args.maxiters, "ebn0_db": args.ebn0,
-                       "sigma": w.sigma, "parallelism": f"{world} independent shard(s), one process per GPU, no collective",
-                       "kernel_variant": args.variant},
+            "config": {"workload": f"{args.code} {args.dtype} LLRs, {what}, resident in HBM, max_iters {args.maxiters} with early "
+                                   f"termination, AWGN Eb/N0 {args.ebn0} dB, {args.pool} random codewords",
+                       "code": args.code, "total_frames": total, "frames_per_gpu": F, "max_iters": args.maxiters, "ebn0_db": args.ebn0,
+                       "sigma": w.sigma, "parallelism": f"{world} contiguous shard(s) of one batch, one process per GPU, no collective",
+                       "kernel_variant": args.variant, "library_build": build_id},
             "roofline": roof, "valu_issue": valu,
             "diag": {"mean_iters_returned": mean_iters, "frame_failure_rate": frame_fail,
                      "edge_visits_per_s": value * 2 * code.paritycheck_sum() * (mean_iters + 1)},
         }
+        if world > 1:
+            result["parity"] = {"frames_compared": compared_total, "mismatches": mism_total,
+                                "note": f"first {compared_rank} frames of every rank's shard against the CPU oracle"}
+            failed = failed or mism_total != 0
 
     # ---- N=1 only: CPU baseline + parity on fixed samples, then the other BASELINE configs --------------
     if rank == 0 and world == 1 and not args.no_cpu:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle                                  # test infrastructure: the checker / CPU baseline
         try:
             native, build = oracle._load(oracle.build_native()), "gcc -O3 -march=native, built on this host"
@@ -233,33 +324,52 @@ def run_rank(args):
         s_all, s_one = min(F, int(args.cpu_frames * scale)), min(F, int(args.cpu_frames * scale) // 16)
         t_all, used, mism = w.compare(args.maxiters, s_all, cores, native)
         t_one, _, mism1 = w.compare(args.maxiters, s_one, 1, native)
+        # and the far end of the batch (the last frames a one-GPU run of config 4 decodes live 137 GB into the buffer)
+        tail = min(F, 2048)
+        _, _, mism_tail = w.compare(args.maxiters, tail, cores, native, offset=F - tail)
         result["cpu_baseline"] = {
             "value": s_all / t_all, "unit": "codewords/s", "cores": used, "kind": "port",
             "one_core": {"value": s_one / t_one, "unit": "codewords/s", "cores": 1, "sample": f"first {s_one} frames, {t_one:.1f} s"},
             "sample": f"first {s_all} of the {F} frames the GPU decoded, same LLR bits, {t_all:.1f} s wall on {used} threads "
                       f"(C port of decode_ms, {build}; the Rust reference cannot be built in this image)"}
-        result["parity"] = {"frames_compared": s_all, "mismatches": mism + mism1}
-        failed = failed or (mism + mism1) != 0
+        result["parity"] = {"frames_compared": s_all + tail, "mismatches": mism + mism1 + mism_tail,
+                            "note": f"first {s_all} and last {tail} frames of the batch against the CPU oracle"}
+        failed = failed or (mism + mism1 + mism_tail) != 0
     elif rank == 0:
         result["cpu_baseline"] = None
 
     if rank == 0 and world == 1 and not args.no_configs:
+        configs = {}
+        if not args.no_cpu:
+            configs["config1_TC128_1frame_50it_3dB"], bad = config1_leg(args)
+            failed = failed or bad != 0
+        # config 4 as each of 8 GPUs sees it: the first and the last 524 288-frame slice of the same buffer
+        if args.code == "TM8192" and F >= 2 * SLICE_FRAMES:
+            for name, lo in (("config4_slice_first", 0), ("config4_slice_last", F - SLICE_FRAMES)):
+                el, kms = w.timed(args.maxiters, args.config_steps, 1, args.variant, frames=(lo, lo + SLICE_FRAMES))
+                mi = float(w.iters[lo:lo + SLICE_FRAMES].double().mean())
+                roof, _ = roofline_of(code, args.code, args.dtype, args.variant, SLICE_FRAMES, kms, mi, build_id)
+                configs[name] = {"workload": f"frames [{lo}, {lo + SLICE_FRAMES}) of the headline batch: the share of one of 8 GPUs",
+                                 "value": SLICE_FRAMES * args.config_steps / el, "unit": "codewords/s", "steps": args.config_steps,
+                                 "ms_per_step": el / args.config_steps * 1e3, "mean_iters_returned": mi, "roofline": roof}
         del w
         torch.cuda.empty_cache()
-        configs = {}
         for key, cname, dtype, frames, ebn0 in EXTRA_CONFIGS:
             c = LDPCCode[cname]
             wl = Workload(c, dtype, frames, ebn0, args.pool, 0, dev)
             el, kms = wl.timed(25, args.config_steps, 1)
-            roof, valu = roofline_of(c, cname, dtype, 0, frames, kms)
             mi, ff = wl.stats()
+            roof, valu = roofline_of(c, cname, dtype, 0, frames, kms, mi, build_id)
             entry = {"workload": f"{cname} {dtype}, {frames} frames resident in HBM, max_iters 25, Eb/N0 {ebn0} dB",
                      "value": frames * args.config_steps / el, "unit": "codewords/s", "steps": args.config_steps,
                      "ms_per_step": el / args.config_steps * 1e3, "mean_iters_returned": mi, "frame_failure_rate": ff,
                      "roofline": roof}
+            if valu:
+                entry["valu_issue"] = {k: valu[k] for k in ("achieved", "frac", "frac_at_measured_clock")}
             if not args.no_cpu:
-                secs, used, mism = wl.compare(25, min(frames, max(256, int(2048 * 8192 / c.n()) // 8)), usable_cores())
-                entry["parity"] = {"frames_compared": min(frames, max(256, int(2048 * 8192 / c.n()) // 8)), "mismatches": mism}
+                sample = min(frames, max(256, int(2048 * 8192 / c.n()) // 8))
+                secs, used, mism = wl.compare(25, sample, usable_cores())
+                entry["parity"] = {"frames_compared": sample, "mismatches": mism}
                 failed = failed or mism != 0
             configs[key] = entry
             del wl
@@ -284,15 +394,19 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "i8"])
     ap.add_argument("--ebn0", type=float, default=2.0)
     ap.add_argument("--maxiters", type=int, default=25)
-    ap.add_argument("--frames-per-gpu", type=int, default=524288)
+    ap.add_argument("--total-frames", type=int, default=4194304,
+                    help="the whole job (BASELINE config 4), split into contiguous shards over the GPUs")
+    ap.add_argument("--frames-per-gpu", type=int, default=0,
+                    help="weak scaling instead: this many frames on EVERY GPU (0 = a share of --total-frames)")
     ap.add_argument("--pool", type=int, default=256, help="distinct random codewords the frames cycle through")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--devices", default="", help="comma-separated device ordinal per local rank (default: rank r -> device r)")
     ap.add_argument("--cpu-frames", type=int, default=16384,
                     help="all-core cpu_baseline sample in TM8192-sized frames (one core: 1/16 of it)")
+    ap.add_argument("--rank-parity-frames", type=int, default=256, help="N > 1: frames of every rank's shard compared with the oracle")
     ap.add_argument("--config-steps", type=int, default=5, help="timed launches per extra BASELINE config")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
-    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2, 3, 5")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1, 2, 3, 5 and the config 4 slices")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

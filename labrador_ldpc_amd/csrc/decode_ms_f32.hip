@@ -9,12 +9,13 @@ hipError_t launch_decode_ms<float>(int code, int variant, const float *llrs, uin
                                    uint32_t *iters, uint8_t *success, size_t batch,
                                    uint32_t maxiters, hipStream_t stream)
 {
+    LDPC_SPLIT_VARIANT();
     // TM8192 runs the pair-ownership kernel by default (6.7 vs 6.35 M codewords/s); `variant` 2 / 4 = the
     // (t, t + M/2) kernel with that many indices per thread, 32 = the pair kernel explicitly (TM8192, TM2048; for TM6144 the compiler's control-flow structurizer turns
     // its four quarter bodies into EXEC-masked loops -- 100x slower, so it is not built)
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
-        if (code == TM8192) return launch_pair<TM8192, float>(llrs, output, iters, success, batch, maxiters, stream);
-        if (code == TM2048) return launch_pair<TM2048, float>(llrs, output, iters, success, batch, maxiters, stream);
+        if (code == TM8192) return launch_pair<TM8192, float>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        if (code == TM2048) return launch_pair<TM2048, float>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
         return hipErrorInvalidConfiguration;
     }
     switch (code) {

@@ -10,8 +10,9 @@ hipError_t launch_decode_ms<int32_t>(int code, int variant, const int32_t *llrs,
                                      uint32_t *iters, uint8_t *success, size_t batch,
                                      uint32_t maxiters, hipStream_t stream)
 {
+    LDPC_SPLIT_VARIANT();
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
-        if (code == TM8192) return launch_pair<TM8192, int32_t>(llrs, output, iters, success, batch, maxiters, stream);
+        if (code == TM8192) return launch_pair<TM8192, int32_t>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
         return hipErrorInvalidConfiguration;
     }
     switch (code) {

@@ -150,7 +150,12 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     using E = float;                                   // LDS exchange element type
     LDPC_DEV static R zero() { return 0.0f; }
     LDPC_DEV static R maxval() { return FLT_MAX; }                              // :72
-    LDPC_DEV static R load(float x) { return x + 0.0f; }                        // -0.0 -> +0.0
+    // -0.0 -> +0.0, and every NaN -> the positive quiet NaN: the reference's hard_bit is `x < 0.0` (:76), false for a NaN
+    // whatever its sign bit, while this kernel reads "negative" from bit 31 -- so a NaN must never carry that bit.  An
+    // LLR NaN makes its variable's marginal and messages NaN for the whole decode (NaN + u, NaN - u: the NaN operand
+    // passes through unchanged; u is never NaN since `<` keeps NaN magnitudes out of min1/min2, :430-434, which is
+    // what v_min3_f32 does with a quiet NaN), and no other NaN can arise (no inf - inf: u is capped at FLT_MAX).
+    LDPC_DEV static R load(float x) { return x != x ? __builtin_nanf("") : x + 0.0f; }
     LDPC_DEV static float store(R x) { return x; }
     LDPC_DEV static R from_lds(float x) { return x; }                           // already canonical
     LDPC_DEV static int bits(R x) { return __float_as_int(x); }
@@ -222,19 +227,43 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // Self-correction test of decoder.rs:422: drop nv iff old != 0 and sign(nv) != sign(old).
     // `old` with its sign flipped when nv is negative is a negative NON-ZERO float exactly then
     // (old is never -0.0), so one three-input bit op (old ^ (nv & 0x80000000)) and one float
-    // compare decide it; "-0.0 < 0" is false, which is the old == 0 case.
+    // compare decide it; "-0.0 < 0" is false, which is the old == 0 case.  (A NaN nv -- always the positive quiet
+    // one, see load() -- leaves t = old: dropped iff old < 0, kept otherwise, as `NaN.hard_bit() == old.hard_bit()`.)
     LDPC_DEV static bool drop(R nv, R old)
     {
         const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
         return __int_as_float(t) < 0.0f;
     }
+    // Self-correction as a CLAMP (FORM 2 / 3).  "Keep nv iff it lies on old's side of zero (any side if old == 0)" is
+    // v = median(nv, 0, X) for any X with X = nv when old == 0 and, when old != 0, the sign of old and |X| >= |nv|.
+    //   FORM 2:  X = nv + old * big   (v_mov + v_fmac_f32, both F class) -- needs big * |old| > |nv| for every nonzero
+    //            old and every nv of the decode, which the caller guarantees (integer messages: big = 2^20; f32: the
+    //            tightened range vote, nocap_limit_for());
+    //   FORM 3:  X = nv + mul_legacy(old, inf): +-inf for every nonzero old (denormals included), 0 * inf = 0 under
+    //            the legacy rule, so no range condition beyond "nothing is NaN or infinite".
+    // One v_med3_f32 replaces the compare and the select: sub, [mov,] fmac, med3 instead of sub, mul, cmp, cndmask.
+    template <int FORM>
+    LDPC_DEV static R clamp_to_side(R nv, R old, float big)
+    {
+        R x, r;
+        if constexpr (FORM == 2) {
+            x = nv;
+            asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "s"(big), "v"(old));
+        } else {
+            asm("v_mul_legacy_f32_e64 %0, %1, %2" : "=v"(x) : "v"(old), "s"(__builtin_inff()));
+            x = x + nv;
+        }
+        asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(nv), "v"(x));
+        return r;
+    }
     // nv, or +0 where drop(nv, old)  (zeroing by EXEC predication instead of v_cndmask measured slower:
     // EXEC writes stall the VALU -- DESIGN.md 4.4)
-    // CARRY: the select through keep_unless_negative (chosen per kernel, see selfcorr_carry())
-    template <bool CARRY>
+    // FORM: 0 = compare + select, 1 = the select through keep_unless_negative (chosen per kernel, see selfcorr_form())
+    // (the clamp forms need a guarantee about the values: self_correct_b)
+    template <int FORM>
     LDPC_DEV static R self_correct(R nv, R old)
     {
-        if constexpr (CARRY) {
+        if constexpr (FORM == 1) {
             const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
             return keep_unless_negative(__int_as_float(t), nv);
         } else {
@@ -247,16 +276,20 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // e_min >= -20 the exponent of the smallest nonzero |LLR| (sums and differences of multiples of g round to
     // multiples of g), so a nonzero value is at least 2^-43 and a product of two cannot underflow; nv == 0 gives
     // v = 0 whichever way the test goes.  An F-class v_mul_f32 in place of the VOP3 bit operation: +1 %.
-    template <bool BOUNDED, bool CARRY = false>
+    // FORM 2 / 3: the clamp forms above (FORM 2 with big = 2^126: the launch's limit then also keeps
+    // 2^126 * 2^-43 above every magnitude of the decode, nocap_limit_for()).
+    template <bool BOUNDED, int FORM = 0>
     LDPC_DEV static R self_correct_b(R nv, R old)
     {
-        if constexpr (BOUNDED) {
+        if constexpr (BOUNDED && FORM >= 2) {
+            return clamp_to_side<FORM>(nv, old, 0x1p126f);
+        } else if constexpr (BOUNDED) {
             float p;
             asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
-            if constexpr (CARRY) return keep_unless_negative(p, nv);
+            if constexpr (FORM == 1) return keep_unless_negative(p, nv);
             else return select_zero(p < 0.0f, nv);
         } else {
-            return self_correct<CARRY>(nv, old);
+            return self_correct<(FORM == 1 ? 1 : 0)>(nv, old);
         }
     }
     // m >= 0 has bit 31 clear, so "m with sign s_all ^ s_own" is one three-input XOR of sign words
@@ -275,7 +308,7 @@ template <> struct Ops<double> {
     using E = double;
     LDPC_DEV static R zero() { return 0.0; }
     LDPC_DEV static R maxval() { return DBL_MAX; }
-    LDPC_DEV static R load(double x) { return x + 0.0; }
+    LDPC_DEV static R load(double x) { return x != x ? __builtin_nan("") : x + 0.0; }      // (NaN -> +qNaN: see Ops<float>::load)
     LDPC_DEV static double store(R x) { return x; }
     LDPC_DEV static R from_lds(double x) { return x; }
     LDPC_DEV static int bits(R x) { return __double2hiint(x); }
@@ -287,18 +320,18 @@ template <> struct Ops<double> {
     LDPC_DEV static R min2(R x, R y)
     {
         const R a = AX ? __builtin_fabs(x) : x, b = AY ? __builtin_fabs(y) : y;
-        return b < a ? b : a;
+        return __builtin_fmin(a, b);              // v_min_f64: a NaN operand is ignored, as the reference's `<` does (:430-434)
     }
     template <bool AX> LDPC_DEV static R min2_cap(R x) { return min2<AX, false>(x, DBL_MAX); }
     template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<false, false>(min2<AX, AY>(x, y), DBL_MAX); }
     template <bool AX, bool AY, bool AZ>
     LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
-    template <bool CARRY>
+    template <int FORM>
     LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
     {
         return (old != 0.0 && (nv < 0.0) != (old < 0.0)) ? 0.0 : nv;
     }
-    template <bool BOUNDED, bool CARRY = false> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<false>(nv, old); }
+    template <bool BOUNDED, int FORM = 0> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<0>(nv, old); }
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
         return __hiloint2double(__double2hiint(m) ^ s_all ^ s_own, __double2loint(m));
@@ -333,10 +366,14 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
         asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
         return p < 0.0f;
     }
-    template <bool CARRY>
+    // FORM 2 / 3: the clamp forms of Ops<float>::clamp_to_side -- exact for every integer message: |nv| < 2^17 and a
+    // nonzero |old| >= 1, so 2^20 * |old| > |nv| always
+    template <int FORM>
     LDPC_DEV static R self_correct(R nv, R old)
     {
-        if constexpr (CARRY) {
+        if constexpr (FORM >= 2) {
+            return Ops<float>::clamp_to_side<FORM>(nv, old, 0x1p20f);
+        } else if constexpr (FORM == 1) {
             float p;
             asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(nv), "v"(old));
             return Ops<float>::keep_unless_negative(p, nv);
@@ -344,7 +381,7 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
             return Ops<float>::select_zero(drop(nv, old), nv);
         }
     }
-    template <bool BOUNDED, bool CARRY = false> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<CARRY>(nv, old); }
+    template <bool BOUNDED, int FORM = 0> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<FORM>(nv, old); }
     template <bool AX>
     LDPC_DEV static R min2_cap(R x)
     {
@@ -396,12 +433,12 @@ template <> struct Ops<int32_t> {
     template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<AX, AY>(x, y); }
     template <bool AX, bool AY, bool AZ>
     LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
-    template <bool CARRY>
+    template <int FORM>
     LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
     {
         return (old != 0 && ((nv ^ old) < 0)) ? 0 : nv;
     }
-    template <bool BOUNDED, bool CARRY = false> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<false>(nv, old); }
+    template <bool BOUNDED, int FORM = 0> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<0>(nv, old); }
     // m >= 0 negated when the product of the other edges' signs is negative (:398-405)
     LDPC_DEV static R apply_sign(R m, int s_all, int s_own)
     {
@@ -511,6 +548,17 @@ constexpr int selfcorr_carry_default()
     return (CODE == TM1280 || CODE == TM1536 || CODE == TM5120) ? 2 : 0;
 }
 
+// Self-correction as a clamp (Ops<float>::clamp_to_side): 0 = no, 2 = v_fmac form, 3 = v_mul_legacy form.  PAIR: the pair
+// kernel (decode_ms_pair.hpp).  Also read by the launcher: with form 2 an f32 kernel's range vote needs the tighter
+// limit of nocap_limit_for().
+template <int CODE, class T, bool PAIR>
+constexpr int selfcorr_med3()
+{
+    if (sizeof(T) > 4 || std::is_same_v<T, int32_t>) return 0;
+    if (PAIR) return LDPC_PAIR_SELFCORR_MED3 >= 0 ? LDPC_PAIR_SELFCORR_MED3 : 0;
+    return LDPC_SELFCORR_MED3 >= 0 ? LDPC_SELFCORR_MED3 : 0;
+}
+
 // Kernels that run iteration 0 as a pass of its own (PEEL_FIRST in the kernel body).  Same-process A/B, M codewords/s:
 //   TC128 f32 1863 -> 2067, i8 1806 -> 2061; TC256 894 -> 1025 / 946 -> 1095; TC512 539 -> 598 / 555 -> 676 (5 dB);
 //   +3-7 % at 3 dB; config 2 (TC512 f32, 2 dB) 104.8 -> 109.2;
@@ -526,6 +574,19 @@ constexpr bool peel_first_default()
     if (CODE == TM2048 || CODE == TM1536 || CODE == TM5120 || CODE == TM6144) return true;
     if (CODE == TM1280) return !std::is_same_v<T, float>;
     return false;
+}
+
+// Codeword groups a workgroup takes per draw from the launch's queue (decode_ms_body, "dynamic distribution"): one
+// for the codes whose decode takes tens of microseconds; eight for the TC codes, whose decodes take one to a few, so
+// that a launch's draws (one same-address atomic each) stay in the tens of millions per second.
+template <int CODE, class T, int IPT>
+constexpr uint32_t claim_chunk()
+{
+#ifdef LDPC_CLAIM_K
+    return LDPC_CLAIM_K;
+#else
+    return CODE <= TC512 ? 8 : 1;
+#endif
 }
 
 // ---- kernel geometry -----------------------------------------------------------------------
@@ -577,7 +638,7 @@ LDPC_DEV int pi_dev(int i, int j)
 template <int CODE, class T, int IPT, bool PF, int LEAN, int JW>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                             uint32_t batch, uint32_t maxiters, float nocap_limit, char *lds, char *stage)
+                             uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, char *lds, char *stage)
 {
     using GEO = Geometry<CODE, T, IPT>;
     using O = Ops<T>;
@@ -622,7 +683,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr bool LITERAL_QUARTER_T = JW >= 0 && LEAN == 0 && IPT == 1;
     const int t = LITERAL_QUARTER_T ? (tid & (M / 4 - 1)) + JW * (M / 4) : (G == 1 ? tid : tid % NT);
     __builtin_assume(t >= 0 && t < NT);
-    // Persistent workgroups: workgroup b decodes codeword groups b, b + gridDim.x, ...
+    // Persistent workgroups over the codeword groups, in chunks of CLAIM_K groups: workgroup b starts with chunk b and
+    // then takes chunks b + gridDim.x, ... (claim == nullptr) or whichever chunk is next in the launch's queue (below)
     const uint32_t n_groups = (batch + G - 1) / G;
     uint32_t cw = blockIdx.x * G + grp;
     bool live = cw < batch;
@@ -791,6 +853,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 
     constexpr int CARRY_SET = LDPC_SELFCORR_CARRY >= 0 ? LDPC_SELFCORR_CARRY : selfcorr_carry_default<CODE>();
     constexpr bool CARRY = CARRY_SET == 2 || (CARRY_SET == 1 && !std::is_same_v<T, float>);
+    // form of the self-correction (Ops::self_correct): the clamp forms where the values allow them -- integer messages
+    // always, f32 only in the clamp-free copy of the loop (its codewords passed the range vote)
+    constexpr int MED3 = selfcorr_med3<CODE, T, false>();
+    constexpr int FORM_U = (MED3 != 0 && sizeof(T) <= 2) ? MED3 : (CARRY ? 1 : 0);
+    constexpr int FORM_B = MED3 != 0 ? MED3 : (CARRY ? 1 : 0);
     auto edge_update = [&](auto S_, auto B_, R x, R uu, auto BND_) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         constexpr bool BND = decltype(BND_)::value != 0 && G == 1;
@@ -799,7 +866,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 #ifdef LDPC_DIAG_NOSELFCORR
         const R nw = nv;
 #else
-        const R nw = BND ? O::template self_correct_b<true, CARRY>(nv, v[S][B]) : O::template self_correct<CARRY>(nv, v[S][B]);
+        const R nw = BND ? O::template self_correct_b<true, FORM_B>(nv, v[S][B]) : O::template self_correct<FORM_U>(nv, v[S][B]);
 #endif
         v[S][B] = nw;
     };
@@ -1197,18 +1264,54 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (par_any < 0) flag_at(it) = 1;
     };
 
+    // DYNAMIC DISTRIBUTION (claim != nullptr).  Iteration counts are data dependent (3 ... max_iters), so equal shares
+    // of the batch are unequal shares of the work: the reference's harness lets every worker pull the next trial until
+    // the job is done (perftest/src/main.rs:39-45), and so do the workgroups here.  `*claim` is the launch's queue head,
+    // zero between launches.  At the START of a chunk's first decode one lane draws a ticket (one atomic per chunk); the
+    // chunk it names, gridDim.x + ticket, is the workgroup's NEXT one, so the atomic's round trip is hidden behind the
+    // first pass of the decode and the value is collected from the returning register afterwards (collect_claim: into an
+    // SGPR for one-wave workgroups, through one LDS word otherwise -- a VGPR held across the whole decode would cost the
+    // large kernels their occupancy).  Every decode of the launch draws at most once and the draws of a launch number
+    // exactly n_chunks, so the holder of ticket n_chunks - 1 knows it drew last and puts the head back to zero: no
+    // memset between launches.  The launcher hands out one queue head per stream (launches of a stream run in order).
+    constexpr uint32_t CLAIM_K = claim_chunk<CODE, T, IPT>();
+    const uint32_t n_chunks = (n_groups + CLAIM_K - 1) / CLAIM_K;
+    const bool dyn = claim != nullptr && maxiters != 0;       // (a decode of zero iterations has no first pass to hide behind)
+    uint32_t ticket = 0;                                      // lane 0 of wave 0: the returning atomic
+    uint32_t next_chunk = 0;                                  // one-wave workgroups: the collected claim (wave-uniform)
+    int *const next_word = reinterpret_cast<int *>(lds + FLAG_OFF + 12);
+    bool fresh = true;                                        // first decode of a chunk (wave-uniform)
+    // (kernels without a peeled first pass would have to carry the ticket into their iteration loop -- TM1280 f32 then
+    // spills inside it -- so they draw at the END of a chunk's first decode instead and wait for the answer there)
+    constexpr bool CLAIM_AHEAD = PEEL_FIRST;
+    auto collect_claim = [&]() LDPC_INLINE {
+        if (dyn && fresh) {
+            if constexpr (GEO::WG == 64) {
+                next_chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x + ticket));
+                if (tid == 0 && ticket == n_chunks - 1) __hip_atomic_store(claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (tid == 0) {
+                *next_word = (int)(gridDim.x + ticket);
+                if (ticket == n_chunks - 1) __hip_atomic_store(claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+
     if constexpr (NOCAP_POSSIBLE) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
-    if (blockIdx.x < n_groups) fetch_llrs(G == 1 ? blockIdx.x : blockIdx.x * G + grp);
-    for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
+    if (blockIdx.x * CLAIM_K < n_groups) fetch_llrs(G == 1 ? blockIdx.x * CLAIM_K : blockIdx.x * CLAIM_K * G + grp);
+    uint32_t chunk = blockIdx.x, g = chunk * CLAIM_K;
+    for (uint32_t first = 1; g < n_groups; first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
     live = cw < batch;
+    if constexpr (CLAIM_AHEAD) {
+        if (dyn && fresh && tid == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!first) fetch_llrs(cw);    // (issuing them before the previous epilogue measured 1.5 % slower here: register allocation)
     begin_codeword(!first);
     if constexpr (PF) {
         // the staged LLRs are in registers (the loads above were waited for by their use in
         // O::load's consumers only after lgkmcnt; make that explicit), now refill the stage
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (g + gridDim.x < n_groups) stage_issue((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
+        if (!dyn && CLAIM_K == 1 && g + gridDim.x < n_groups) stage_issue((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
     }
 
     // Codewords that share a wave (G > 1) finish at different iterations: a finished one
@@ -1228,6 +1331,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             if constexpr (LEAN == 1) check_phase_lean(0u, IC<1>{});
             else if (check_phase(0u, CAP_, IC<1>{})) { done = true; ok = true; iters = 0; }
         }
+        collect_claim();
         if constexpr (G == 1) { if (done) return; }
         it0 = 1;
     }
@@ -1296,7 +1400,21 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     }
     if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
     if constexpr (NOCAP_POSSIBLE) { if (t == 0) cap_flag() = 0; }
+    if constexpr (!CLAIM_AHEAD) {
+        if (dyn && fresh && tid == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        collect_claim();
+    }
     LDPC_SYNC();                  // every wave is done with the flags before the next codeword resets them
+    // next group: the rest of this chunk, then the claimed chunk (collected during this chunk's first decode, many
+    // barriers ago) or the static stride
+    ++g;
+    fresh = false;
+    if (g % CLAIM_K == 0 || g >= n_groups) {
+        if (dyn) chunk = GEO::WG == 64 ? next_chunk : (uint32_t)__builtin_amdgcn_readfirstlane(*next_word);
+        else chunk += gridDim.x;
+        g = chunk < n_chunks ? chunk * CLAIM_K : n_groups;
+        fresh = true;
+    }
     }                             // persistent loop over codeword groups
 }
 
@@ -1336,7 +1454,7 @@ template <int CODE, class T, int IPT, bool PF, int LEAN>
 __global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                 uint32_t batch, uint32_t maxiters, float nocap_limit)
+                 uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim)
 {
     using GEO = Geometry<CODE, T, IPT>;
     constexpr int Q = GEO::M / 4;
@@ -1350,17 +1468,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // arrivals of the whole workgroup, whichever copy a wave runs).
     if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
         else
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
     } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
         const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
-        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
-        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
-        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
-        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
     } else {
-        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds, stage);
+        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
     }
 }
 

@@ -7,6 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "decode_ms_kernel.hpp"
 #include "decode_ms_pair.hpp"
@@ -15,7 +19,8 @@ namespace ldpc {
 
 // Launch the decoder for `batch` frames on `stream`.  `variant` = 0 picks the tuned default
 // IPT (indices per thread) for the code; a positive value requests that IPT explicitly and
-// yields hipErrorInvalidConfiguration if it was not instantiated.
+// yields hipErrorInvalidConfiguration if it was not instantiated.  VARIANT_STATIC added to either
+// distributes the codewords over the workgroups by a fixed stride instead of through the launch's queue.
 template <class T>
 hipError_t launch_decode_ms(int code, int variant, const T *llrs, uint8_t *output, uint32_t *iters,
                             uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
@@ -28,11 +33,57 @@ hipError_t launch_decode_ms(int code, int variant, const T *llrs, uint8_t *outpu
 // L * 7^maxiters * 1.4 (rounding included).  Requiring that to stay under 2^127 gives the limit below:
 // 2^55 at the benchmark's 25 iterations, less than any real LLR from 45 iterations on (then every codeword
 // simply takes the clamped copy of the loop).  0 = never.
-inline float nocap_limit_for(uint32_t maxiters)
+//
+// `clamp_form`: the kernel runs the self-correction of bounded codewords as v = med3(nv, 0, nv + old * 2^126)
+// (Ops<float>::clamp_to_side, form 2), which additionally needs 2^126 * |old| > |nv| for every nonzero old: with every
+// nonzero value of the decode >= 2^-43 (the vote's lower bound 2^-20 on nonzero |LLR|, times the 2^-23 granularity)
+// that is 2^83 > 1.4 L 7^maxiters, i.e. log2 L < 82.5 - log2(7) maxiters: 2^12 at the benchmark's 25 iterations.
+inline float nocap_limit_for(uint32_t maxiters, bool clamp_form = false)
 {
-    const double log2_limit = 126.0 - 2.8074 * (double)maxiters;      // log2(7) = 2.80735...
-    if (log2_limit < -120.0) return 0.0f;
+    double log2_limit = 126.0 - 2.8074 * (double)maxiters;            // log2(7) = 2.80735...
+    if (clamp_form && 82.5 - 2.8074 * (double)maxiters < log2_limit) log2_limit = 82.5 - 2.8074 * (double)maxiters;
+    if (log2_limit < -20.0) return 0.0f;                               // (below the vote's lower bound: no codeword passes)
     return (float)__builtin_ldexp(1.0, (int)__builtin_floor(log2_limit));
+}
+
+// `variant` flag: fixed-stride distribution of the codewords (no queue); the rest of `variant` selects the kernel
+constexpr int VARIANT_STATIC = 256;
+
+// The queue head of a launch's dynamic codeword distribution (decode_ms_body, "dynamic distribution"): a device word that
+// is zero between launches -- the kernel that drew from it puts it back.  One word per (device, stream): launches of a
+// stream run in order, so they can share it; launches of different streams may overlap, so they must not.  nullptr
+// (= fixed stride) while `stream` is being captured into a graph (a graph can be replayed on any stream, next to
+// anything), for the per-thread default stream (one handle, many streams), when LABRADOR_LDPC_HIP_STATIC is set, or if
+// the word cannot be allocated.
+inline uint32_t *claim_counter(hipStream_t stream)
+{
+    static const bool off = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_STATIC"); return e && *e && *e != '0'; }();
+    if (off || stream == hipStreamPerThread) return nullptr;
+    if (stream != nullptr) {                     // (the legacy stream cannot be captured; asking would disturb a global-mode capture)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    struct Block { uint32_t *base = nullptr; unsigned used = 0; };
+    constexpr unsigned PER_BLOCK = 1024;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, uint32_t *> heads;
+    static std::map<int, Block> blocks;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = heads.find({dev, stream});
+    if (it != heads.end()) return it->second;
+    Block &b = blocks[dev];
+    if (b.base == nullptr || b.used == PER_BLOCK) {
+        uint32_t *p = nullptr;
+        if (hipMalloc(&p, PER_BLOCK * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, PER_BLOCK * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+        b.base = p;
+        b.used = 0;
+    }
+    uint32_t *head = b.base + b.used++;
+    heads[{dev, stream}] = head;
+    return head;
 }
 
 // Resident workgroups per device for one instantiation (occupancy x compute units), cached.
@@ -58,7 +109,7 @@ int resident_workgroups()
 // Launch one instantiation (IPT indices per thread; LEAN 1 = register-lean check phase, 2 = in-place messages).
 template <int CODE, class T, int IPT, int LEAN>
 hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                      size_t batch, uint32_t maxiters, hipStream_t stream)
+                      size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
 {
     using GEO = Geometry<CODE, T, IPT>;
     // LLR staging (PF) is implemented but measured SLOWER than plain loads at the start of each
@@ -73,17 +124,23 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // hundreds of codewords and the data-dependent iteration counts average out.  Where several
     // fit per CU the grid is 16x the resident set so that the hardware dispatcher still balances
     // (measured on TM2048: 21.7 / 25.0 / 27.2 / 27.7 M codewords/s at 1x / 2x / 8x / 64x).
+    // With the launch's queue (claim_counter) the grid is the resident set itself: the workgroups balance the work by
+    // drawing from the queue, and nothing is paid for starting workgroups beyond the first wave of them.
     const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN>();
-    size_t grid = resident <= 256 ? resident : resident * 16;
-    if (grid > groups) grid = groups;
+    uint32_t *claim = (static_stride || maxiters == 0) ? nullptr : claim_counter(stream);
+    constexpr size_t K = claim_chunk<CODE, T, IPT>();
+    const size_t chunks = (groups + K - 1) / K;
+    size_t grid = (resident <= 256 || claim != nullptr) ? resident : resident * 16;
+    if (grid > chunks) grid = chunks;
+    constexpr bool clamp_form = std::is_same_v<T, float> && selfcorr_med3<CODE, T, false>() == 2;
     hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
-                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters));
+                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim);
     return hipGetLastError();
 }
 
 template <int CODE, class T, int IPT>
 hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                      size_t batch, uint32_t maxiters, hipStream_t stream)
+                      size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
 {
     // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
     // is TM5120 (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB) and the narrow types of TM1280.  Measured slower
@@ -91,14 +148,14 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // TM1280 i8 / i16: 168 -> 116 VGPRs, four waves per SIMD instead of three: 68.4 -> 71.0 (its f32 kernel 70.5 -> 69.5: not).
     constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
     constexpr int LEAN = (CODE == TM5120 || (CODE == TM1280 && narrow)) && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
-    return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream);
+    return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
 }
 
 // Pair-ownership kernel (decode_ms_pair.hpp): one workgroup per CU-resident codeword, persistent.
 constexpr int VARIANT_PAIR = 32;
 template <int CODE, class T>
 hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                       size_t batch, uint32_t maxiters, hipStream_t stream)
+                       size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
 {
     using GEO = PairGeometry<CODE, T>;
     if (batch == 0) return hipSuccess;
@@ -114,28 +171,34 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
         resident = per_cu * cus;
         cached[dev].store(resident, std::memory_order_relaxed);
     }
-    size_t grid = resident <= 256 ? (size_t)resident : (size_t)resident * 16;
+    uint32_t *claim = (static_stride || maxiters == 0) ? nullptr : claim_counter(stream);
+    size_t grid = (resident <= 256 || claim != nullptr) ? (size_t)resident : (size_t)resident * 16;
     if (grid > batch) grid = batch;
+    constexpr bool clamp_form = std::is_same_v<T, float> && selfcorr_med3<CODE, T, true>() == 2;
     hipLaunchKernelGGL((decode_ms_pair_kernel<CODE, T>), dim3((unsigned)grid), dim3(GEO::NT), 0, stream,
-                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters));
+                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim);
     return hipGetLastError();
 }
 
 // one `case` of the dispatch switch: default IPT plus optional alternatives
+// (expects `variant` with VARIANT_STATIC already split off into `static_stride`: LDPC_SPLIT_VARIANT)
 #define LDPC_CASE(CODE, T, DEF, ...)                                                             \
     case CODE: {                                                                                 \
         constexpr int alts[] = {DEF, ##__VA_ARGS__};                                             \
         return dispatch_ipt<CODE, T, DEF, ##__VA_ARGS__>(variant == 0 ? alts[0] : variant, llrs, \
                                                          output, iters, success, batch, maxiters, \
-                                                         stream);                                \
+                                                         stream, static_stride);                 \
     }
+#define LDPC_SPLIT_VARIANT()                                                                     \
+    const bool static_stride = variant >= 0 && (variant & VARIANT_STATIC) != 0;                  \
+    if (static_stride) variant &= ~VARIANT_STATIC
 
 template <int CODE, class T, int... IPTS>
 hipError_t dispatch_ipt(int ipt, const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                        size_t batch, uint32_t maxiters, hipStream_t stream)
+                        size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
 {
     hipError_t r = hipErrorInvalidConfiguration;
-    (void)((ipt == IPTS ? (r = launch_one<CODE, T, IPTS>(llrs, output, iters, success, batch, maxiters, stream), true)
+    (void)((ipt == IPTS ? (r = launch_one<CODE, T, IPTS>(llrs, output, iters, success, batch, maxiters, stream, static_stride), true)
                         : false) || ...);
     return r;
 }

@@ -66,7 +66,7 @@ constexpr bool all_exchanged_are_pi(const Prototype &p)
 template <int CODE, class T, int JW>
 LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                                   uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                                  uint32_t batch, uint32_t maxiters, float nocap_limit, char *lds)
+                                  uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, char *lds)
 {
     using GEO = PairGeometry<CODE, T>;
     using O = Ops<T>;
@@ -176,7 +176,10 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #ifdef LDPC_DIAG_NOSELFCORR
         v[S][B] = nv;
 #else
-        v[S][B] = O::template self_correct_b<(decltype(BND_)::value != 0), (LDPC_PAIR_SELFCORR_CARRY != 0)>(nv, v[S][B]);   // :422-425
+        constexpr bool BND = decltype(BND_)::value != 0;
+        constexpr int MED3 = selfcorr_med3<CODE, T, true>();
+        constexpr int FORM = (MED3 != 0 && (BND || sizeof(T) <= 2)) ? MED3 : (LDPC_PAIR_SELFCORR_CARRY != 0 ? 1 : 0);
+        v[S][B] = O::template self_correct_b<BND, FORM>(nv, v[S][B]);                  // :422-425
 #endif
     };
 
@@ -354,10 +357,27 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #ifdef LDPC_DIAG_STAMPS
     const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime(), loop_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (uint32_t g = blockIdx.x, first = 1; g < n_groups; g += gridDim.x, first = 0) {
+    // Dynamic distribution of the codewords (claim != nullptr): see decode_ms_body in decode_ms_kernel.hpp.  Thread 0
+    // draws a ticket at the start of each decode; the codeword it names, gridDim.x + ticket, is this workgroup's NEXT
+    // one.  The returning register is collected after the first pass (collect_claim) into one LDS word, which every wave
+    // reads when the decode ends -- many barriers later -- in time for the early LLR fetch.
+    const bool dyn = claim != nullptr && maxiters != 0;
+    uint32_t ticket = 0;
+    int *const next_word = reinterpret_cast<int *>(lds + FLAG_OFF + 12);
+    auto collect_claim = [&]() LDPC_INLINE {
+        if constexpr (JW == 0) {
+            if (dyn && t == 0) {
+                *next_word = (int)(gridDim.x + ticket);
+                if (ticket == n_groups - 1) __hip_atomic_store(claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the launch's last draw
+            }
+        }
+    };
+    for (uint32_t g = blockIdx.x; g < n_groups;) {
         cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-        (void)first;                              // (FETCH_EARLY: this codeword's LLR loads were issued behind the previous epilogue)
-        if constexpr (!FETCH_EARLY) fetch_llrs(cw);
+        if constexpr (JW == 0) {
+            if (dyn && t == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (!FETCH_EARLY) fetch_llrs(cw);   // (FETCH_EARLY: this codeword's LLR loads were issued behind the previous epilogue)
         begin_codeword();
         bool done = false, ok = false;
         uint32_t iters = maxiters;
@@ -372,6 +392,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{}, IC<1>{});
                 LDPC_SYNC();
                 check_phase(0u, CAP_, IC<1>{});
+                collect_claim();
                 it0 = 1;
             }
             for (uint32_t it = it0;; ++it) {
@@ -394,6 +415,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #endif
                 if (it > 0 && t == 0) flag_at(it - 1) = 0;
                 check_phase(it, CAP_, IC<0>{});
+                if constexpr (LDPC_PAIR_PEEL_FIRST == 0) { if (it == 0) collect_claim(); }
 #ifdef LDPC_DIAG_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 t3 = __builtin_amdgcn_s_memtime();
@@ -415,7 +437,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         }
 #endif
         // the next codeword's LLR loads, issued before this one's epilogue (fixed cost per codeword 2.55 -> 2.12 us)
-        if (FETCH_EARLY && g + gridDim.x < n_groups) fetch_llrs((uint32_t)__builtin_amdgcn_readfirstlane((int)(g + gridDim.x)));
+        const uint32_t g_next = dyn ? (uint32_t)__builtin_amdgcn_readfirstlane(*next_word) : g + gridDim.x;
+        if (FETCH_EARLY && g_next < n_groups) fetch_llrs(g_next);
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
         // s_bitreplicate doubles every bit), then bit-reversed per byte
@@ -445,6 +468,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         });
         if (t == 0) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; cap_flag() = 0; }
         LDPC_SYNC();
+        g = g_next;
     }
 #ifdef LDPC_DIAG_STAMPS
     if ((t & 63) == 0 && blockIdx.x < 256) {
@@ -458,15 +482,15 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 template <int CODE, class T>
 __global__ void __launch_bounds__((PairGeometry<CODE, T>::NT))
 decode_ms_pair_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters_out,
-                      uint8_t *__restrict__ success_out, uint32_t batch, uint32_t maxiters, float nocap_limit)
+                      uint8_t *__restrict__ success_out, uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim)
 {
     using GEO = PairGeometry<CODE, T>;
     __shared__ __attribute__((aligned(16))) char lds[GEO::LDS_BYTES];
     const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8);          // quarter of this wave's indices
-    if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
-    else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
-    else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
-    else decode_ms_pair_body<CODE, T, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, lds);
+    if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    else decode_ms_pair_body<CODE, T, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
 }
 
 }  // namespace ldpc

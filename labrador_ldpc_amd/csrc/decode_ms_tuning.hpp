@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
@@ -27,6 +27,14 @@
 // -1 = per code (selfcorr_carry_default()), 0 = off, 1 = i8/i16, 2 = f32 too.
 #ifndef LDPC_SELFCORR_CARRY
 #define LDPC_SELFCORR_CARRY -1
+#endif
+// Self-correction as a clamp, v = med3(nv, 0, nv + old * big) (Ops<float>::clamp_to_side): -1 = per kernel
+// (selfcorr_med3()), 0 = off, 2 = v_fmac form, 3 = v_mul_legacy form.
+#ifndef LDPC_SELFCORR_MED3
+#define LDPC_SELFCORR_MED3 -1
+#endif
+#ifndef LDPC_PAIR_SELFCORR_MED3
+#define LDPC_PAIR_SELFCORR_MED3 -1
 #endif
 // pair kernel: where the next codeword's LLR loads are issued
 #ifndef LDPC_PAIR_FETCH_EARLY

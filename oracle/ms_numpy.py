@@ -121,7 +121,10 @@ def decode_ms(st: Structure, llrs: np.ndarray, n: int, maxiters: int):
         nv = sub(vae, u)
         keep = ((nv < zero) == (v < zero)) | (v == zero)
         v = np.where(keep, nv, zero).astype(wt)
-        a = np.concatenate([mag(v), np.broadcast_to(pad, (len(live), 1))], axis=1)[:, st.by_check]   # [f, C, maxdeg]
+        am = mag(v)
+        if is_float:
+            am = np.where(np.isnan(am), pad, am)  # a NaN magnitude never passes the `<` of :430 / :433: it is +inf to the minima
+        a = np.concatenate([am, np.broadcast_to(pad, (len(live), 1))], axis=1)[:, st.by_check]   # [f, C, maxdeg]
         a.sort(axis=2)
         min1 = np.minimum(a[:, :, 0], maxval).astype(wt)
         min2 = np.minimum(a[:, :, 1], maxval).astype(wt)

@@ -96,7 +96,21 @@ def test_f32_corner_values(code):
     llrs[6, ::7] = np.inf
     llrs[7, ::11] = -np.inf
     llrs[8] = np.where(rng.random(n) < 0.5, np.float32(3.4e38), np.float32(-3.4e38))
+    # NaN LLRs: hard_bit is `x < 0.0` (src/decoder.rs:76), false for a NaN whatever its sign bit; quiet and signalling, both signs,
+    # a whole frame of them, NaN next to infinities (tests/golden/nan_*.npz freeze the same for every code)
+    qp, qn, sp, sn = np.array([0x7FC00000, 0xFFC00000, 0x7FA00000, 0xFFA00001], dtype=np.uint32).view(np.float32)
+    u = llrs.view(np.uint32)
+    for row, pats in ((9, [qp]), (10, [qn]), (11, [sp]), (12, [sn]), (13, [qn, qp, sn, sp])):
+        for j, pos in enumerate(rng.permutation(n)[: 1 if row < 13 else 24]):
+            u[row, pos] = np.array(pats[j % len(pats)]).view(np.uint32)
+    u[14, :] = np.array(qn).view(np.uint32)
+    u[15, ::2] = np.array(sn).view(np.uint32)
+    llrs[16, ::13] = np.inf
+    u[16, 5::13] = np.array(qn).view(np.uint32)
+    assert np.isnan(llrs[9:17]).any(axis=1).all()
     _compare(code, llrs, 20)
+    for variant in {LDPCCode.TM8192: (2, 32 + 256)}.get(code, (256,)):
+        _compare(code, llrs, 20, variant=variant)
 
 
 @pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TC256, LDPCCode.TC512, LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048,
@@ -165,7 +179,16 @@ def test_f64_corner_values(code):
     llrs[4] *= 1e307
     llrs[5, ::7] = np.inf
     llrs[6, ::11] = -np.inf
+    # NaN LLRs (src/decoder.rs:85: `x < 0.0`): quiet / signalling, both signs, a whole frame
+    qp, qn, sp, sn = np.array([0x7FF8000000000000, 0xFFF8000000000000, 0x7FF4000000000000, 0xFFF4000000000001], dtype=np.uint64).view(np.float64)
+    u = llrs.view(np.uint64)
+    for row, pats in ((7, [qp]), (8, [qn]), (9, [sp]), (10, [sn]), (11, [qn, qp, sn, sp])):
+        for j, pos in enumerate(rng.permutation(code.n())[: 1 if row < 11 else 24]):
+            u[row, pos] = np.array(pats[j % len(pats)]).view(np.uint64)
+    u[12, :] = np.array(qn).view(np.uint64)
+    assert np.isnan(llrs[7:13]).any(axis=1).all()
     _compare(code, llrs, 20)
+    _compare(code, llrs, 20, variant=100)
 
 
 F64_VARIANTS = [(LDPCCode.TC128, 17), (LDPCCode.TC256, 17), (LDPCCode.TC512, 17), (LDPCCode.TM1280, 17), (LDPCCode.TM1280, 33),
@@ -278,3 +301,55 @@ def test_bounded_mode_at_the_small_end_of_its_llr_range(code):
     zeros[:, ::3] = 0.0
     zeros[:, 1::3] = -0.0
     _compare(code, zeros, 25)
+
+
+@pytest.mark.parametrize("code", ALL, ids=lambda c: c.name)
+@pytest.mark.parametrize("dtype", [np.float32, np.int8], ids=["f32", "i8"])
+def test_queue_fed_and_fixed_stride_distribution_agree(code, dtype):
+    """The workgroups of a launch take their codewords from the launch's queue (one atomic per chunk of codeword groups,
+    decode_ms_kernel.hpp "dynamic distribution"; the reference's harness does the same with its workers,
+    perftest/src/main.rs:39-45) or, with VARIANT_STATIC = 256, by a fixed stride.  Which workgroup decodes a frame must not
+    matter: batch sizes around the chunk size and the resident grid, launches back to back on one stream (the queue head puts
+    itself back to zero), and the oracle on the last one."""
+    import torch
+    rng = np.random.default_rng(0x51 + int(code))
+    base, _ = oracle.awgn_llrs(code, rng, 40, {0: 4.0, 1: 3.5, 2: 3.0, 3: 3.6, 4: 2.6, 5: 2.0, 6: 3.3, 7: 2.3, 8: 1.9}[int(code)], dtype,
+                               scale=8.0, lim=31)
+    ref = oracle.decode_ms_batch(code, base, 25)
+    sizes = (1, 7, 9, 255, 257, 1000, 3073, 6000) if code.n() <= 2048 else (1, 2, 255, 257, 511, 513, 800)
+    for b in sizes:
+        idx = (np.arange(b) * 7) % len(base)
+        d = torch.from_numpy(base[idx]).cuda()
+        for variant in (0, 256, 0, 0):
+            out, it, ok = (t.cpu().numpy() for t in code.decode_ms_batch(d, 25, variant=variant))
+            assert (out == ref[0][idx]).all() and (it == ref[1][idx]).all() and (ok == ref[2][idx]).all(), (b, variant)
+    out, it, ok = (t.cpu().numpy() for t in code.decode_ms_batch(d, 0))          # max_iters 0: no queue (nothing to hide the draw behind)
+    assert not out.any() and (it == 0).all() and (ok == 0).all()
+
+
+def test_launches_on_different_streams_have_their_own_queue():
+    """Launches of one stream run in order and share a queue head; launches of different streams may overlap and must not.
+    Eight streams decode different batches at once, repeatedly; every frame must come out decoded exactly once."""
+    import torch
+    code = LDPCCode.TM2048
+    rng = np.random.default_rng(0x57)
+    base, _ = oracle.awgn_llrs(code, rng, 64, 2.2, np.float32)
+    ref = oracle.decode_ms_batch(code, base, 25)
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    jobs = []
+    for rep in range(3):
+        for si, st in enumerate(streams):
+            b = 700 + 301 * si + rep
+            idx = (np.arange(b) * (si + 3) + rep) % len(base)
+            d = torch.from_numpy(base[idx]).cuda()
+            out = torch.full((b, code.output_len()), 0xEE, dtype=torch.uint8, device="cuda")
+            it = torch.full((b,), -1, dtype=torch.int32, device="cuda")
+            ok = torch.full((b,), 7, dtype=torch.uint8, device="cuda")
+            jobs.append((st, idx, d, out, it, ok))
+    torch.cuda.synchronize()
+    for st, idx, d, out, it, ok in jobs:
+        with torch.cuda.stream(st):
+            code.decode_ms_batch(d, 25, output=out, iters=it, success=ok, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    for st, idx, d, out, it, ok in jobs:
+        assert (out.cpu().numpy() == ref[0][idx]).all() and (it.cpu().numpy() == ref[1][idx]).all() and (ok.cpu().numpy() == ref[2][idx]).all()

@@ -17,8 +17,11 @@ def test_decode_kernels_have_uniform_control_flow():
     import scan_kernels
     table = scan_kernels.scan()
     assert len(table) >= 60
+    # (round 3: the queue draw -- one lane's atomic, its collection, the reset -- adds four small EXEC-guarded regions per
+    # quarter-specialised body, and the compiler also writes some wave-uniform jumps as s_cbranch_execnz: the in-place f64
+    # kernels reach 21-25, the mis-structured kernels of round 2 had 119 and more)
     bad = {k: v for k, v in table.items()
-           if v[1] > 16 and "decode_ms_f64_kernel" not in k[1]}     # the f64 workspace fallback (variant 100) is a plain loop kernel
+           if v[1] > 40 and "decode_ms_f64_kernel" not in k[1]}     # the f64 workspace fallback (variant 100) is a plain loop kernel
     assert not bad, f"kernels with EXEC-masked loops (mis-structured control flow): {bad}"
 
 

@@ -37,6 +37,9 @@
 #ifndef KEBN0
 #define KEBN0 2.0
 #endif
+#ifndef KLIMIT
+#define KLIMIT 0x1p12f        // the launcher's nocap_limit_for(25, clamp form)
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main()
 {
@@ -51,17 +54,40 @@ int main()
     CK(launch_awgn<KT>(pool, 1, llrs, (int)n, F, sigma, 8.f, 31, 0x1DBCull + code, nullptr));
     using GEO = Geometry<code, KT, KIPT>;
     unsigned groups = (unsigned)((F + GEO::G - 1) / GEO::G);
+    {   // the launcher's grid (decode_ms_launch.hpp): the resident set with the queue, 16x it (where several workgroups share a CU) without
+        int per_cu = 1, cus = 256;
+#if KPAIR
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_pair_kernel<code, KT>, PairGeometry<code, KT>::NT, 0));
+        const unsigned chunks = groups;
+#else
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>, GEO::WG, 0));
+        const unsigned K = claim_chunk<code, KT, KIPT>(), chunks = (groups + K - 1) / K;
+#endif
+        CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+        unsigned resident = (unsigned)(per_cu * cus);
+#ifdef KSTATIC
+        unsigned grid = resident <= 256 ? resident : resident * 16;
+#else
+        unsigned grid = resident;
+#endif
 #ifdef KGRID
-    if (groups > KGRID) groups = KGRID;          // persistent workgroups
+        grid = KGRID;
+#endif
+        groups = grid < chunks ? grid : chunks;
+        printf("occupancy %d workgroups per CU x %d CUs; grid %u\n", per_cu, cus, groups);
+    }
+    uint32_t *claim = nullptr;
+#if !defined(KSTATIC)
+    CK(hipMalloc(&claim, 4)); CK(hipMemset(claim, 0, 4));       // the launch's queue head (self-resetting)
 #endif
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
 #if KPAIR
-        hipLaunchKernelGGL((decode_ms_pair_kernel<code, KT>), dim3(groups), dim3(PairGeometry<code, KT>::NT), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, 0x1p55f);
+        hipLaunchKernelGGL((decode_ms_pair_kernel<code, KT>), dim3(groups), dim3(PairGeometry<code, KT>::NT), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim);
 #else
-        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, 0x1p55f);
+        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim);
 #endif
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -109,6 +135,7 @@ int main()
                    perq[q][2] / 1024 / (iters_total / 256), perq[q][3] / 1024 / (iters_total / 256));
     }
 #endif
+    if (claim) { uint32_t left = 1; CK(hipMemcpy(&left, claim, 4, hipMemcpyDeviceToHost)); if (left != 0) printf("QUEUE HEAD NOT RESET: %u\n", left); }
     printf("%scode %d T%zu ipt %d pf %d grid %u frames %zu: %.3f ms -> %.3f M cw/s | mean iters %.3f success %.5f | hash %016llx\n", KPAIR ? "PAIR " : "", code, sizeof(KT), KIPT, (int)KPF, groups, F, best,
            F / best / 1e3, si / F, sk / F, h);
     return 0;
