@@ -98,25 +98,28 @@ class Workload:
                                   variant=variant)
 
     def timed(self, maxiters, steps, warmup, variant=0, barrier=lambda: None, frames=None):
-        """(wall seconds of `steps` launches, mean kernel ms from HIP events on the launch stream); `frames` = (lo, hi):
-        only that slice of the batch."""
+        """(wall seconds of `steps` launches, mean launch duration in ms from HIP events on the launch stream); `frames` =
+        (lo, hi): only that slice of the batch."""
         import numpy as np
         import torch
         for _ in range(warmup):
             self.step(maxiters, variant, frames)
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # ONE pair of events around the timed launches (decode_ms_batch launches on torch's current stream, where the events
+        # sit): an event between two launches is a barrier packet of its own, and for launches of well under a millisecond
+        # (config 2) the bubble it opens is a tenth of the kernel -- the kernels of a stream already run in order
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for a, b in ev:                     # decode_ms_batch launches on torch's current stream, where the events sit
-            a.record()
+        a.record()
+        for _ in range(steps):
             self.step(maxiters, variant, frames)
-            b.record()
+        b.record()
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
-        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return elapsed, a.elapsed_time(b) / steps
 
     def stats(self):
         return float(self.iters.double().mean()), 1.0 - float(self.succ.double().mean())
@@ -357,12 +360,17 @@ def run_rank(args):
         for key, cname, dtype, frames, ebn0 in EXTRA_CONFIGS:
             c = LDPCCode[cname]
             wl = Workload(c, dtype, frames, ebn0, args.pool, 0, dev)
-            el, kms = wl.timed(25, args.config_steps, 1)
+            # enough back-to-back launches for ~100 ms of timed region after ~25 ms of warm-up: a launch of well under a
+            # millisecond (config 2) is otherwise timed while the device is still coming out of idle -- its duration falls by
+            # 15 % over the first few milliseconds of continuous work (profiles/r03_kbench/tc_trace.txt)
+            _, probe_ms = wl.timed(25, 1, 1)
+            steps = int(min(200, max(args.config_steps, 100.0 / max(probe_ms, 1e-3))))
+            el, kms = wl.timed(25, steps, max(1, steps // 4))
             mi, ff = wl.stats()
             roof, valu = roofline_of(c, cname, dtype, 0, frames, kms, mi, build_id)
             entry = {"workload": f"{cname} {dtype}, {frames} frames resident in HBM, max_iters 25, Eb/N0 {ebn0} dB",
-                     "value": frames * args.config_steps / el, "unit": "codewords/s", "steps": args.config_steps,
-                     "ms_per_step": el / args.config_steps * 1e3, "mean_iters_returned": mi, "frame_failure_rate": ff,
+                     "value": frames * steps / el, "unit": "codewords/s", "steps": steps, "warmup": max(1, steps // 4),
+                     "ms_per_step": el / steps * 1e3, "mean_iters_returned": mi, "frame_failure_rate": ff,
                      "roofline": roof}
             if valu:
                 entry["valu_issue"] = {k: valu[k] for k in ("achieved", "frac", "frac_at_measured_clock")}

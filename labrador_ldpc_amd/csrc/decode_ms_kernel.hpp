@@ -150,12 +150,39 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     using E = float;                                   // LDS exchange element type
     LDPC_DEV static R zero() { return 0.0f; }
     LDPC_DEV static R maxval() { return FLT_MAX; }                              // :72
-    // -0.0 -> +0.0, and every NaN -> the positive quiet NaN: the reference's hard_bit is `x < 0.0` (:76), false for a NaN
-    // whatever its sign bit, while this kernel reads "negative" from bit 31 -- so a NaN must never carry that bit.  An
-    // LLR NaN makes its variable's marginal and messages NaN for the whole decode (NaN + u, NaN - u: the NaN operand
-    // passes through unchanged; u is never NaN since `<` keeps NaN magnitudes out of min1/min2, :430-434, which is
-    // what v_min3_f32 does with a quiet NaN), and no other NaN can arise (no inf - inf: u is capped at FLT_MAX).
-    LDPC_DEV static R load(float x) { return x != x ? __builtin_nanf("") : x + 0.0f; }
+    // -0.0 -> +0.0, and every NaN -> +inf.
+    // NaN LLRs: the reference's hard_bit is `x < 0.0` (:76), false for a NaN whatever its sign bit, while this kernel reads
+    // "negative" from bit 31, so a sign-carrying NaN must not reach the registers.  Clearing that bit on the common path
+    // (compare + select, integer bit tricks, an asm bundle, a ballot and a cold fix-up branch: all tried) cost the kernels at
+    // their register limit 20-50 spilled registers.  But a NaN LLR and a +inf LLR are THE SAME INPUT to decode_ms -- every
+    // output bit, the iteration count and the success flag agree:
+    //   * the marginal is NaN + u resp. inf + u, for ever (u is finite: +-min1 / min2 <= maxval, :391-405): never `< 0`, so
+    //     hard bit 0 (:457, :469) and no contribution to the parity (:445);
+    //   * every message along the variable's edges is NaN - u resp. inf - u = the same again; it is kept by the
+    //     self-correction (old v is 0, then itself: `hard_bit() ==` holds, :422), is never `< 0` (no sign contribution, :439),
+    //     and its magnitude NaN resp. inf passes neither `< min1` nor `< min2` (:430, :433) nor `== min1` (:391): the checks
+    //     see an edge that takes no part in the minima, and its own u is min1 either way.
+    // So the load maps NaN to +inf with one v_min_f32 -- minNum(NaN, inf) = inf; the add before it quiets a signalling NaN,
+    // which minNum would otherwise turn into a quiet NaN.  +inf LLRs were always part of the contract (tests since round 1).
+    // (Written with the builtin, not as inline asm: an asm statement between a load and its use makes the compiler wait
+    // for every LLR load on the spot -- ten serialised L2 round trips per variable phase in the register-lean kernel.)
+#ifdef LDPC_DIAG_NONAN
+    LDPC_DEV static R load(float x) { return x + 0.0f; }                         // (kbench: what does the NaN mapping cost?)
+    LDPC_DEV static R canon_late(R x) { return x + 0.0f; }
+#else
+    LDPC_DEV static R load(float x) { return __builtin_fminf(x + 0.0f, __builtin_inff()); }
+    // LATE canonicalisation, for the kernels where the load-time form does not come for free.  Without the NaN mapping the
+    // compiler never materialised `llr = raw + 0.0`: it kept the raw registers and folded the `+ 0.0` into the copy that starts
+    // each marginal's accumulation.  A two-operation load() cannot be folded that way; it becomes a second set of values, and
+    // the two kernels that sit at a forced register limit (TM1280 f32 at 168, the register-lean TM5120 f32 at 128) spilled
+    // 20-45 more registers for it (-17 % / -16 %, profiles/r03_kbench/kb4.txt).  Those kernels keep the RAW LLR (keep_raw), add
+    // it as it is, and canonicalise the finished marginal instead: raw + u1 + ... equals llr + u1 + ... as a VALUE at every
+    // step (a -0.0 addend behaves like +0.0 unless everything is -0.0), `+ 0.0` then turns a -0.0 result into +0.0, and a NaN
+    // LLR leaves a NaN marginal, which min(., inf) maps to the +inf marginal a +inf LLR would have left.  One more v_min per
+    // transmitted column and iteration, no extra registers.
+    LDPC_DEV static R canon_late(R x) { return __builtin_fminf(x + 0.0f, __builtin_inff()); }
+#endif
+    LDPC_DEV static R keep_raw(float x) { return x; }
     LDPC_DEV static float store(R x) { return x; }
     LDPC_DEV static R from_lds(float x) { return x; }                           // already canonical
     LDPC_DEV static int bits(R x) { return __float_as_int(x); }
@@ -308,7 +335,9 @@ template <> struct Ops<double> {
     using E = double;
     LDPC_DEV static R zero() { return 0.0; }
     LDPC_DEV static R maxval() { return DBL_MAX; }
-    LDPC_DEV static R load(double x) { return x != x ? __builtin_nan("") : x + 0.0; }      // (NaN -> +qNaN: see Ops<float>::load)
+    LDPC_DEV static R load(double x) { return __builtin_fmin(x + 0.0, __builtin_inf()); }      // -0.0 -> +0.0, NaN -> +inf: see Ops<float>::load
+    LDPC_DEV static R canon_late(R x) { return __builtin_fmin(x + 0.0, __builtin_inf()); }
+    LDPC_DEV static R keep_raw(double x) { return x; }
     LDPC_DEV static double store(R x) { return x; }
     LDPC_DEV static R from_lds(double x) { return x; }
     LDPC_DEV static int bits(R x) { return __double2hiint(x); }
@@ -346,6 +375,8 @@ template <> struct Ops<double> {
 template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.rs:42-59
     LDPC_DEV static R maxval() { return (float)HI; }
     LDPC_DEV static R load(I x) { return (float)(int)x; }                       // never -0.0
+    LDPC_DEV static R canon_late(R x) { return x; }
+    LDPC_DEV static R keep_raw(I x) { return (float)(int)x; }
     LDPC_DEV static R clamp(R x) { return __builtin_amdgcn_fmed3f(x, (float)LO, (float)HI); }
     LDPC_DEV static R add(R a, R b) { return clamp(a + b); }                    // saturating_add
     LDPC_DEV static R sub(R a, R b) { return clamp(a - b); }                    // saturating_sub
@@ -416,6 +447,8 @@ template <> struct Ops<int32_t> {
     LDPC_DEV static R zero() { return 0; }
     LDPC_DEV static R maxval() { return 0x7FFFFFFF; }                           // :63
     LDPC_DEV static R load(int32_t x) { return x; }
+    LDPC_DEV static R canon_late(R x) { return x; }
+    LDPC_DEV static R keep_raw(int32_t x) { return x; }
     LDPC_DEV static float store(R x) { return __int_as_float(x); }
     LDPC_DEV static R from_lds(float x) { return __float_as_int(x); }
     LDPC_DEV static int bits(R x) { return x; }
@@ -548,16 +581,33 @@ constexpr int selfcorr_carry_default()
     return (CODE == TM1280 || CODE == TM1536 || CODE == TM5120) ? 2 : 0;
 }
 
-// Self-correction as a clamp (Ops<float>::clamp_to_side): 0 = no, 2 = v_fmac form, 3 = v_mul_legacy form.  PAIR: the pair
-// kernel (decode_ms_pair.hpp).  Also read by the launcher: with form 2 an f32 kernel's range vote needs the tighter
-// limit of nocap_limit_for().
-template <int CODE, class T, bool PAIR>
+// Self-correction as a clamp (Ops<float>::clamp_to_side) in decode_ms_kernel: 0 = no, 2 = v_fmac form, 3 = v_mul_legacy form
+// (the pair kernel has a template parameter for it).  Also read by the launcher: with form 2 an f32 kernel's range vote needs
+// the tighter limit of nocap_limit_for().
+// Same-process A/B (tools/kbench.hip, profiles/r03_kbench/kb1.txt, kb2.txt; identical outputs), M codewords/s:
+//   i8, form 2: TM6144 11.65 -> 11.94, TC512 (3 dB) 312.5 -> 318.4, TM2048 46.90 -> 47.09 (form 3: 47.26), TM1536 61.79 -> 61.96;
+//   the register-lean kernels lose: TM5120 i8 19.07 -> 18.86 (4 dB), 7.34 -> 7.23 (2 dB), TM1280 i8 73.25 -> 72.75;
+//   f32 (only in a clamp-free copy of the loop): TM2048 form 3 37.07 -> 37.52, form 2 37.19; TC512 (with the loop) 130.9 -> 137.0.
+template <int CODE, class T>
 constexpr int selfcorr_med3()
 {
     if (sizeof(T) > 4 || std::is_same_v<T, int32_t>) return 0;
-    if (PAIR) return LDPC_PAIR_SELFCORR_MED3 >= 0 ? LDPC_PAIR_SELFCORR_MED3 : 0;
-    return LDPC_SELFCORR_MED3 >= 0 ? LDPC_SELFCORR_MED3 : 0;
+    if (LDPC_SELFCORR_MED3 >= 0) return LDPC_SELFCORR_MED3;
+    constexpr bool narrow = sizeof(T) <= 2;
+    if (CODE == TM5120 || (CODE == TM1280 && narrow)) return 0;       // the register-lean kernels (launch_one)
+    if (narrow) return CODE == TM2048 ? 3 : 2;
+    return (CODE == TM2048 || CODE == TC512) ? 3 : 0;                  // f32: the kernels with a clamp-free loop (NOCAP_POSSIBLE)
 }
+
+// The in-phase verdict of the register-lean kernels (LEAN_VERDICT in the kernel body).  Measured and refuted in round 3
+// (profiles/r03_kbench/kb3.txt): carrying the rows' state across the vote costs 67 spilled registers at the lean kernels'
+// 128-register budget -- TM5120 i8 19.04 -> 17.66 (4 dB), 7.33 -> 6.71 (2 dB), f32 13.7 -> 9.6 M codewords/s.  Off.
+template <int CODE, class T>
+constexpr bool lean_verdict_default() { return false; }
+
+// Packed LLR registers in the register-lean kernels of the narrow types (PACKED_LLR in the kernel body)
+template <int CODE, class T>
+constexpr bool packed_llr_default() { return true; }
 
 // Kernels that run iteration 0 as a pass of its own (PEEL_FIRST in the kernel body).  Same-process A/B, M codewords/s:
 //   TC128 f32 1863 -> 2067, i8 1806 -> 2061; TC256 894 -> 1025 / 946 -> 1095; TC512 539 -> 598 / 555 -> 676 (5 dB);
@@ -576,16 +626,19 @@ constexpr bool peel_first_default()
     return false;
 }
 
-// Codeword groups a workgroup takes per draw from the launch's queue (decode_ms_body, "dynamic distribution"): one
-// for the codes whose decode takes tens of microseconds; eight for the TC codes, whose decodes take one to a few, so
-// that a launch's draws (one same-address atomic each) stay in the tens of millions per second.
+// Most codeword groups a workgroup takes per draw from the launch's queue (decode_ms_body, "dynamic distribution").  The
+// draws of a launch are atomics on ONE address, and the device sustains 85-90 million of those per second whatever else it
+// does (measured: TC512 at 5 dB through the queue with two groups per draw stops at 172 M codewords/s against 600 with the
+// fixed stride, TC128 with four codewords per group at 672 against 1 900; profiles/r03_kbench/rates_all_queue_everywhere.txt).
+// So the queue is for the codes whose decode takes tens of microseconds, with enough groups per draw to stay an order of
+// magnitude under that ceiling even at high SNR; the launcher (launch_cfg) takes fewer per draw when a launch is short.
 template <int CODE, class T, int IPT>
 constexpr uint32_t claim_chunk()
 {
 #ifdef LDPC_CLAIM_K
     return LDPC_CLAIM_K;
 #else
-    return CODE <= TC512 ? 8 : 1;
+    return CODE == TM2048 ? 4 : (CODE == TM5120 || CODE == TM6144) ? 2 : 1;
 #endif
 }
 
@@ -638,7 +691,7 @@ LDPC_DEV int pi_dev(int i, int j)
 template <int CODE, class T, int IPT, bool PF, int LEAN, int JW>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                             uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, char *lds, char *stage)
+                             uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k, char *lds, char *stage)
 {
     using GEO = Geometry<CODE, T, IPT>;
     using O = Ops<T>;
@@ -708,7 +761,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // Measured: TM2048 41.3 -> 43.0 M codewords/s; TM6144 -1.6 %, TM1536 -0.7 %, TM1280 -11 %, and 34 spilled VGPRs
     // with two indices per thread (the second copy of the loop is not free); TC512: 19 spilled VGPRs at the four-waves budget,
     // 108 -> 100 M codewords/s on config 2.  Hence TM2048 only.
-    constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && CODE == TM2048 && G == 1 && LEAN == 0 && IPT == 1;
+    // (TC512: refused in round 2, when its kernel was capped at 128 registers and the second loop spilled; at today's 139 it
+    // does not, and with the clamp form of the self-correction the clamp-free loop is worth +4.6 % at 1 048 576 frames, +2.4 %
+    // on config 2's 65 536: 130.9 -> 137.0, 118.7 -> 121.6 M codewords/s, profiles/r03_kbench/kb4.txt)
+#ifdef LDPC_NOCAP_ALSO
+    constexpr bool NOCAP_CODE = CODE == TM2048 || CODE == TC512 || CODE == LDPC_NOCAP_ALSO;     // (kbench experiment)
+#else
+    constexpr bool NOCAP_CODE = CODE == TM2048 || CODE == TC512;
+#endif
+    constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && NOCAP_CODE && G == 1 && LEAN == 0 && IPT == 1;
     auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(gbase + FLAG_OFF + 8); };
 
     // Byte offset, inside one block's M*SZ-byte LDS region, of the variable that check
@@ -791,7 +852,32 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // codeword's hard-decision epilogue and this one's state initialisation, whose ~200
     // instructions cover the HBM latency; the registers are the ones `llr` vacates when a decode ends.
     T lraw[IPT][NTX];
+    bool cap_wave = false;        // one-wave workgroups: the clamp vote of the current codeword (wave-uniform)
+    // The register-lean kernels of the narrow LLR types keep their LLRs as PACKED raw values -- four i8 or two i16 per register,
+    // three / five registers for TM5120's ten -- instead of re-reading them from L2 in every variable phase, as the lean f32
+    // kernel must (it has no registers to spare): TM5120 i8 19.04 -> 20.64 (4 dB), 7.33 -> 7.84 M codewords/s (2 dB), no spills
+    // (profiles/r03_kbench/kb3.txt).  Unpacking is a shift-and-sign-extend folded into the conversion to f32.
+#ifdef LDPC_LEAN_PACKED_LLR
+    constexpr bool PACKED_LLR = LDPC_LEAN_PACKED_LLR != 0 && LEAN == 1 && sizeof(T) <= 2;
+#else
+    constexpr bool PACKED_LLR = LEAN == 1 && sizeof(T) <= 2 && packed_llr_default<CODE, T>();
+#endif
+    constexpr int PER_REG = PACKED_LLR ? 4 / (int)sizeof(T) : 1, PK_BITS = 8 * (int)sizeof(T);
+    unsigned llr_pk[IPT][(NTX + PER_REG - 1) / PER_REG];
     auto fetch_llrs = [&](uint32_t c) LDPC_INLINE {
+        if constexpr (PACKED_LLR) {
+            const uint32_t cc = c < batch ? c : batch - 1;
+            using UT = std::conditional_t<sizeof(T) == 1, uint8_t, uint16_t>;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                constexpr int S = decltype(S_)::value;
+                static_for<0, (NTX + PER_REG - 1) / PER_REG>([&](auto W_) LDPC_INLINE { llr_pk[S][decltype(W_)::value] = 0; });
+                static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                    constexpr int C = decltype(C_)::value;
+                    const unsigned b = (unsigned)(UT)(llrs + (size_t)cc * N)[(unsigned)(C * M + S * NT) + (unsigned)t];
+                    llr_pk[S][C / PER_REG] |= b << (PK_BITS * (C % PER_REG));
+                });
+            });
+        }
         if constexpr (LEAN) return;
         unsigned tu = (unsigned)t;
         asm volatile("" : "+v"(tu));
@@ -806,6 +892,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 
     // Iteration 0 as a pass of its own (see check_phase): per kernel, peel_first_default()
     constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN != 2;
+    // float LLRs: canonicalise the finished marginals instead of the LLRs (Ops<float>::canon_late) -- the register-lean kernels,
+    // which re-read their LLRs in every variable phase, and TM1280 f32
+    constexpr bool LATE_CANON = std::is_floating_point_v<T> && (LEAN != 0 || (CODE == TM1280 && IPT == 1));
     constexpr bool ZERO_FREE = PEEL_FIRST;
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
         if constexpr (PF) {
@@ -829,10 +918,17 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 }
             });
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
+            if constexpr (INPLACE) {
+                // in-place mode keeps the exchanged columns' marginals only as sign words in LDS, written by the first
+                // variable phase: a decode of ZERO iterations (marginals all zero, decoder.rs:374, :466-474) never runs one
+                // and would hard-decide the previous codeword's words (found by the NaN goldens' max_iters = 0 leg, round 3)
+                if (maxiters == 0)
+                    static_for<0, NXC>([&](auto X_) LDPC_INLINE { *reinterpret_cast<int *>(gbase + hi_off(decltype(X_)::value) + i * 4) = 0; });
+            }
             static_for<0, NTX>([&](auto C_) LDPC_INLINE {
                 constexpr int C = decltype(C_)::value;
                 if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * TSZ));
-                else if constexpr (!LEAN) llr[S][C] = O::load(lraw[S][C]);     // fetched by fetch_llrs()
+                else if constexpr (!LEAN) llr[S][C] = LATE_CANON ? O::keep_raw(lraw[S][C]) : O::load(lraw[S][C]);     // fetched by fetch_llrs()
             });
         });
         (void)tu;
@@ -845,7 +941,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     big |= !(a <= nocap_limit) || (a != 0.0f && a < 0x1p-20f);     // NaN counts as out of range
                 });
             });
-            if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
+            if constexpr (GEO::WG == 64) cap_wave = __ballot(big) != 0;          // one wave = one codeword: no LDS word needed
+            else if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
         } else {
             if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;  // (the clamp-vote word, unused here)
         }
@@ -855,7 +952,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr bool CARRY = CARRY_SET == 2 || (CARRY_SET == 1 && !std::is_same_v<T, float>);
     // form of the self-correction (Ops::self_correct): the clamp forms where the values allow them -- integer messages
     // always, f32 only in the clamp-free copy of the loop (its codewords passed the range vote)
-    constexpr int MED3 = selfcorr_med3<CODE, T, false>();
+    constexpr int MED3 = selfcorr_med3<CODE, T>();
     constexpr int FORM_U = (MED3 != 0 && sizeof(T) <= 2) ? MED3 : (CARRY ? 1 : 0);
     constexpr int FORM_B = MED3 != 0 ? MED3 : (CARRY ? 1 : 0);
     auto edge_update = [&](auto S_, auto B_, R x, R uu, auto BND_) LDPC_INLINE {
@@ -911,7 +1008,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int C = decltype(C_)::value;
                 R acc = O::zero();
                 if constexpr (C < NTX) {
-                    if constexpr (LEAN) acc = O::load((llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(C * M) + (unsigned)i]);
+                    if constexpr (PACKED_LLR) acc = O::load((T)(llr_pk[S][C / PER_REG] >> (PK_BITS * (C % PER_REG))));
+                    else if constexpr (LEAN) {
+                        const T x = (llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(C * M) + (unsigned)i];
+                        acc = LATE_CANON ? O::keep_raw(x) : O::load(x);
+                    }
                     else acc = llr[S][C];
                 }
                 if constexpr (INPLACE) {
@@ -925,6 +1026,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                             acc = O::add(acc, ue[B]);                                  // :408
                         }
                     });
+                    if constexpr (LATE_CANON && C < NTX) acc = O::canon_late(acc);   // (see Ops<float>::canon_late)
                     if constexpr (col_slot(P, C) < 0) va[S][C] = acc;               // exchanged columns: only the sign word is kept (hi array)
                     static_for<0, NB>([&](auto B_) LDPC_INLINE {                       // nv = va - u (:421), in place
                         constexpr int B = decltype(B_)::value;
@@ -950,6 +1052,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                         else acc = O::add(acc, u[S][B]);
                     }
                 });
+                if constexpr (LATE_CANON && C < NTX) acc = O::canon_late(acc);     // (see Ops<float>::canon_late)
                 va[S][C] = acc;
                 constexpr int cs = col_slot(P, C);
                 if constexpr (cs >= 0) {
@@ -981,6 +1084,12 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr int WG_VERDICT_SET = LDPC_WG_VERDICT >= 0 ? LDPC_WG_VERDICT
                                  : (CODE == TM1536 || (CODE == TM1280 && !(sizeof(T) <= 2))) ? 1 : 0;
     constexpr bool WG_VERDICT = WG_VERDICT_SET != 0 && !WAVE_VERDICT && G == 1 && IPT == 1 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
+    // The register-lean check phase cannot hold its marginals between a parity pass and the updates (that is what makes it
+    // lean), but it can split the other way: pass A = requests, edge updates, parities and sign words of ALL rows; vote
+    // through the flag and a third barrier; pass B = exclusive minima, next u and their stores, skipped on success (it reads
+    // only v, which is in registers).  LDPC_LEAN_VERDICT: measured in round 3 (see lean_verdict_default()).
+    constexpr bool LEAN_VERDICT = (LDPC_LEAN_VERDICT >= 0 ? LDPC_LEAN_VERDICT != 0 : lean_verdict_default<CODE, T>()) && LEAN == 1 && G == 1 && LDPC_DIAG_EARLY_EXIT;
+    constexpr bool IN_PHASE_VERDICT = WAVE_VERDICT || WG_VERDICT || LEAN_VERDICT;
     // Iteration 0 peeled (PEEL_FIRST; at high SNR a decode is two or three passes, and the first one is cheaper than
     // the rest): u = 0 and v = 0 make every new v the marginal itself (decoder.rs:421-425
     // with u == 0 and v == 0: x - 0, kept), so the pass needs no LDS reads in its variable phase and no
@@ -1127,11 +1236,35 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // Register-lean check phase (LEAN): one check row at a time, its edges in chunks of six; the u
     // of an exchanged edge is read back from the LDS slot it was stored to, nothing per edge but v
     // (and the u of local edges) stays live between chunks; addresses are recomputed for the store.
-    auto check_phase_lean = [&](uint32_t it, auto FIRST_) LDPC_INLINE {
+    auto check_phase_lean = [&](uint32_t it, auto FIRST_) LDPC_INLINE -> bool {
         constexpr bool FIRST = decltype(FIRST_)::value != 0;      // iteration 0 peeled: u == 0, v == 0 (see check_phase)
         int par_any = 0;
         int tb = t * SZ;
         asm volatile("" : "+v"(tb));
+        int sgn_row[IPT][NROWS];                                  // (LEAN_VERDICT: the rows' sign words, carried from pass A to pass B)
+        // pass B of one row: exclusive minima, next u, stores (decoder.rs:391-405 of the next iteration)
+        auto finish_row = [&](auto S_, auto R_, int sgn) LDPC_INLINE {
+            constexpr int S = decltype(S_)::value, Rw = decltype(R_)::value;
+            constexpr int D = row_degree(P, Rw);
+            R a[D], e[D];
+            static_for<0, D>([&](auto J_) LDPC_INLINE {
+                constexpr int J = decltype(J_)::value, B = row_block(P, Rw, J);
+                a[J] = v[S][B];
+            });
+            exclusive_min<O, D, true>(a, e);                                           // :391-395, :430-435
+            static_for<0, D>([&](auto J_) LDPC_INLINE {
+                constexpr int J = decltype(J_)::value;
+                constexpr int B = row_block(P, Rw, J);
+                const R un = O::apply_sign(e[J], sgn, O::bits(v[S][B]) & (int)0x80000000);   // :398-405
+                constexpr int slot = exch_slot(P, B);
+                if constexpr (slot >= 0) {
+                    constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
+                    lds_store(off + wire(IC<B>{}, S_, tb), O::store(un));
+                } else {
+                    u[S][B] = un;
+                }
+            });
+        };
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             constexpr int S = decltype(S_)::value;
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
@@ -1174,28 +1307,23 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                         sgn ^= O::bits(v[S][B]) & (int)0x80000000;                     // :439-441
                     });
                 });
-                R a[D], e[D];
-                static_for<0, D>([&](auto J_) LDPC_INLINE {
-                    constexpr int J = decltype(J_)::value, B = row_block(P, Rw, J);
-                    a[J] = v[S][B];
-                });
-                exclusive_min<O, D, true>(a, e);                                       // :391-395, :430-435
-                static_for<0, D>([&](auto J_) LDPC_INLINE {
-                    constexpr int J = decltype(J_)::value;
-                    constexpr int B = row_block(P, Rw, J);
-                    const R un = O::apply_sign(e[J], sgn, O::bits(v[S][B]) & (int)0x80000000);   // :398-405
-                    constexpr int slot = exch_slot(P, B);
-                    if constexpr (slot >= 0) {
-                        constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
-                        lds_store(off + wire(IC<B>{}, S_, tb), O::store(un));
-                    } else {
-                        u[S][B] = un;
-                    }
-                });
+                if constexpr (LEAN_VERDICT) sgn_row[S][Rw] = sgn;
+                else finish_row(S_, R_, sgn);
                 par_any |= par;
             });
         });
-        if (par_any < 0) flag_at(it) = 1;
+        if constexpr (LEAN_VERDICT) {
+            if (__ballot(par_any < 0) != 0 && (tid & 63) == 0) flag_at(it) = 1;
+            LDPC_SYNC();
+            if (flag_at(it) == 0) return true;                                         // :453: every check of the codeword holds
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                static_for<0, NROWS>([&](auto R_) LDPC_INLINE { finish_row(S_, R_, sgn_row[decltype(S_)::value][decltype(R_)::value]); });
+            });
+            return false;
+        } else {
+            if (par_any < 0) flag_at(it) = 1;
+            return false;
+        }
     };
 
     // In-place check phase (LEAN == 2): as the lean one, but an exchanged edge's slot already holds
@@ -1274,9 +1402,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // large kernels their occupancy).  Every decode of the launch draws at most once and the draws of a launch number
     // exactly n_chunks, so the holder of ticket n_chunks - 1 knows it drew last and puts the head back to zero: no
     // memset between launches.  The launcher hands out one queue head per stream (launches of a stream run in order).
-    constexpr uint32_t CLAIM_K = claim_chunk<CODE, T, IPT>();
-    const uint32_t n_chunks = (n_groups + CLAIM_K - 1) / CLAIM_K;
     const bool dyn = claim != nullptr && maxiters != 0;       // (a decode of zero iterations has no first pass to hide behind)
+    const uint32_t CLAIM_K = dyn && claim_k != 0 ? claim_k : 1u;          // groups per draw, chosen by the launcher (a fixed stride goes group by group)
+    const uint32_t n_chunks = (n_groups + CLAIM_K - 1) / CLAIM_K;
     uint32_t ticket = 0;                                      // lane 0 of wave 0: the returning atomic
     uint32_t next_chunk = 0;                                  // one-wave workgroups: the collected claim (wave-uniform)
     int *const next_word = reinterpret_cast<int *>(lds + FLAG_OFF + 12);
@@ -1296,9 +1424,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
-    if constexpr (NOCAP_POSSIBLE) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
+    if constexpr (NOCAP_POSSIBLE && GEO::WG != 64) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
     if (blockIdx.x * CLAIM_K < n_groups) fetch_llrs(G == 1 ? blockIdx.x * CLAIM_K : blockIdx.x * CLAIM_K * G + grp);
-    uint32_t chunk = blockIdx.x, g = chunk * CLAIM_K;
+    uint32_t chunk = blockIdx.x, g = chunk * CLAIM_K, g_end = g + CLAIM_K;       // [g, g_end): the rest of the current chunk
     for (uint32_t first = 1; g < n_groups; first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
     live = cw < batch;
@@ -1328,7 +1456,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (G == 1 || !done) variable_phase(IC<1>{});
         LDPC_SYNC();
         if (G == 1 || !done) {
-            if constexpr (LEAN == 1) check_phase_lean(0u, IC<1>{});
+            if constexpr (LEAN == 1) { if (check_phase_lean(0u, IC<1>{})) { done = true; ok = true; iters = 0; } }
             else if (check_phase(0u, CAP_, IC<1>{})) { done = true; ok = true; iters = 0; }
         }
         collect_claim();
@@ -1339,7 +1467,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (it > 0) LDPC_SYNC();  // u of the exchanged blocks and the parity vote are visible (iteration 0: barrier below)
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
-            if constexpr (!WAVE_VERDICT && !WG_VERDICT) {
+            if constexpr (!IN_PHASE_VERDICT) {
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
             }
             if (!done && it == maxiters) { done = true; }
@@ -1352,15 +1480,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if constexpr (!WAVE_VERDICT) { if (it > 0 && t == 0) flag_at(it - 1) = 0; }
         if (G == 1 || !done) {
             if constexpr (LEAN == 2) check_phase_inplace(it);
-            else if constexpr (LEAN == 1) check_phase_lean(it, IC<0>{});
+            else if constexpr (LEAN == 1) { if (check_phase_lean(it, IC<0>{})) { done = true; ok = true; iters = it; } }
             else if (check_phase(it, CAP_, IC<0>{})) { done = true; ok = true; iters = it; }      // (wave verdict, decoder.rs:453-463)
         }
-        if constexpr ((WAVE_VERDICT || WG_VERDICT) && G == 1) { if (done) break; }
+        if constexpr (IN_PHASE_VERDICT && G == 1) { if (done) break; }
     }
     };
     LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
     if constexpr (NOCAP_POSSIBLE) {
-        if (__builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
+        if (GEO::WG == 64 ? cap_wave : __builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
         else iterate(IC<0>{});
     } else {
         iterate(IC<1>{});
@@ -1399,7 +1527,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
     }
     if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
-    if constexpr (NOCAP_POSSIBLE) { if (t == 0) cap_flag() = 0; }
+    if constexpr (NOCAP_POSSIBLE && GEO::WG != 64) { if (t == 0) cap_flag() = 0; }
     if constexpr (!CLAIM_AHEAD) {
         if (dyn && fresh && tid == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         collect_claim();
@@ -1409,10 +1537,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // barriers ago) or the static stride
     ++g;
     fresh = false;
-    if (g % CLAIM_K == 0 || g >= n_groups) {
+    if (g >= g_end || g >= n_groups) {
         if (dyn) chunk = GEO::WG == 64 ? next_chunk : (uint32_t)__builtin_amdgcn_readfirstlane(*next_word);
         else chunk += gridDim.x;
         g = chunk < n_chunks ? chunk * CLAIM_K : n_groups;
+        g_end = g + CLAIM_K;
         fresh = true;
     }
     }                             // persistent loop over codeword groups
@@ -1454,7 +1583,7 @@ template <int CODE, class T, int IPT, bool PF, int LEAN>
 __global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                 uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim)
+                 uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k)
 {
     using GEO = Geometry<CODE, T, IPT>;
     constexpr int Q = GEO::M / 4;
@@ -1468,17 +1597,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // arrivals of the whole workgroup, whichever copy a wave runs).
     if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
         else
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
         const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
-        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
-        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
-        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
-        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     } else {
-        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds, stage);
+        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     }
 }
 

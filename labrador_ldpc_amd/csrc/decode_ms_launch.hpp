@@ -126,15 +126,25 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // (measured on TM2048: 21.7 / 25.0 / 27.2 / 27.7 M codewords/s at 1x / 2x / 8x / 64x).
     // With the launch's queue (claim_counter) the grid is the resident set itself: the workgroups balance the work by
     // drawing from the queue, and nothing is paid for starting workgroups beyond the first wave of them.
+    // Which distribution: the queue for workgroups of 8 waves and more (TM2048 +3.0 %, TM5120 +1.4-1.8 %, TM8192 +0.9 % over
+    // the fixed stride: their decodes take tens of microseconds and a workgroup is expensive to start); the fixed stride on
+    // the 16x grid for the smaller ones, where the hardware dispatcher is a queue that costs no atomics (the TC codes' draws
+    // would hit the device's ceiling of ~85 M same-address atomics per second: claim_chunk()).
     const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN>();
-    uint32_t *claim = (static_stride || maxiters == 0) ? nullptr : claim_counter(stream);
-    constexpr size_t K = claim_chunk<CODE, T, IPT>();
+    constexpr bool queue_fed = GEO::WG >= 512;
+    uint32_t *claim = (static_stride || maxiters == 0 || !queue_fed) ? nullptr : claim_counter(stream);
+    // groups per draw: at least ~8 draws per resident workgroup, so that the last chunks are a small part of a short launch
+    size_t K = 1;
+    if (claim != nullptr) {
+        K = claim_chunk<CODE, T, IPT>();
+        while (K > 1 && groups < 8 * K * resident) K /= 2;
+    }
     const size_t chunks = (groups + K - 1) / K;
     size_t grid = (resident <= 256 || claim != nullptr) ? resident : resident * 16;
     if (grid > chunks) grid = chunks;
-    constexpr bool clamp_form = std::is_same_v<T, float> && selfcorr_med3<CODE, T, false>() == 2;
+    constexpr bool clamp_form = std::is_same_v<T, float> && selfcorr_med3<CODE, T>() == 2;
     hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
-                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim);
+                       llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim, (uint32_t)K);
     return hipGetLastError();
 }
 
@@ -153,20 +163,18 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
 
 // Pair-ownership kernel (decode_ms_pair.hpp): one workgroup per CU-resident codeword, persistent.
 constexpr int VARIANT_PAIR = 32;
-template <int CODE, class T>
-hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                       size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+template <int CODE, class T, int FORM>
+hipError_t launch_pair_form(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                            size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
 {
     using GEO = PairGeometry<CODE, T>;
-    if (batch == 0) return hipSuccess;
-    if (batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
     static std::atomic<int> cached[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     int resident = cached[dev].load(std::memory_order_relaxed);
     if (resident == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_pair_kernel<CODE, T>, GEO::NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_pair_kernel<CODE, T, FORM>, GEO::NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident = per_cu * cus;
         cached[dev].store(resident, std::memory_order_relaxed);
@@ -174,10 +182,28 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
     uint32_t *claim = (static_stride || maxiters == 0) ? nullptr : claim_counter(stream);
     size_t grid = (resident <= 256 || claim != nullptr) ? (size_t)resident : (size_t)resident * 16;
     if (grid > batch) grid = batch;
-    constexpr bool clamp_form = std::is_same_v<T, float> && selfcorr_med3<CODE, T, true>() == 2;
-    hipLaunchKernelGGL((decode_ms_pair_kernel<CODE, T>), dim3((unsigned)grid), dim3(GEO::NT), 0, stream,
+    constexpr bool clamp_form = std::is_same_v<T, float> && FORM == 2;
+    hipLaunchKernelGGL((decode_ms_pair_kernel<CODE, T, FORM>), dim3((unsigned)grid), dim3(GEO::NT), 0, stream,
                        llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim);
     return hipGetLastError();
+}
+
+template <int CODE, class T>
+hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                       size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+{
+    if (batch == 0) return hipSuccess;
+    if (batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if constexpr (std::is_same_v<T, float>) {
+        // f32: the v_fmac clamp form (+10 %) narrows the range vote to |LLR| <= 2^floor(82.5 - log2(7) max_iters) -- 2^12 at the
+        // benchmark's 25 iterations, 2^3 at 28; beyond that real LLRs would fall out of the clamp-free loop altogether, so longer
+        // decodes run the v_mul_legacy form (+7 %), whose vote is the clamp-free loop's own
+        if (nocap_limit_for(maxiters, true) >= 8.0f)
+            return launch_pair_form<CODE, T, 2>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        return launch_pair_form<CODE, T, 3>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+    } else {
+        return launch_pair_form<CODE, T, pair_form_default<T>()>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+    }
 }
 
 // one `case` of the dispatch switch: default IPT plus optional alternatives

@@ -63,7 +63,8 @@ constexpr bool all_exchanged_are_pi(const Prototype &p)
     return true;
 }
 
-template <int CODE, class T, int JW>
+// FORM: the self-correction's form (Ops::self_correct): 0 = compare + select, 2 / 3 = the clamp forms
+template <int CODE, class T, int JW, int FORM>
 LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                                   uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                                   uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, char *lds)
@@ -81,7 +82,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     // odd rotations read their two marginals as halves of two aligned 64-bit pairs (see check_phase): +12 % for
     // i8 (8.0 -> 9.0 M codewords/s), but the wider destinations cost f32 nine spilled VGPRs (6.7 -> 6.5)
     constexpr bool ODD_B64 = LDPC_PAIR_ODD_B64 >= 0 ? LDPC_PAIR_ODD_B64 != 0 : !std::is_same_v<T, float>;
-    constexpr int LOCAL_IN_VAR = LDPC_PAIR_LOCAL_IN_VAR >= 0 ? LDPC_PAIR_LOCAL_IN_VAR : (std::is_same_v<T, float> ? 8 : 4);
+    constexpr int LOCAL_IN_VAR = LDPC_PAIR_LOCAL_IN_VAR >= 0 ? LDPC_PAIR_LOCAL_IN_VAR : (std::is_same_v<T, float> ? 10 : 8);
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
 
@@ -176,10 +177,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #ifdef LDPC_DIAG_NOSELFCORR
         v[S][B] = nv;
 #else
+        // the clamp forms need a guarantee about the values: integer messages always have it, f32 only the codewords of the
+        // clamp-free loop (they passed the range vote)
         constexpr bool BND = decltype(BND_)::value != 0;
-        constexpr int MED3 = selfcorr_med3<CODE, T, true>();
-        constexpr int FORM = (MED3 != 0 && (BND || sizeof(T) <= 2)) ? MED3 : (LDPC_PAIR_SELFCORR_CARRY != 0 ? 1 : 0);
-        v[S][B] = O::template self_correct_b<BND, FORM>(nv, v[S][B]);                  // :422-425
+        constexpr int F = (FORM >= 2 && (BND || sizeof(T) <= 2)) ? FORM : (LDPC_PAIR_SELFCORR_CARRY != 0 ? 1 : 0);
+        v[S][B] = O::template self_correct_b<BND, F>(nv, v[S][B]);                     // :422-425
 #endif
     };
 
@@ -479,7 +481,18 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 #endif
 }
 
-template <int CODE, class T>
+// Self-correction form of the pair kernel.  The clamp forms (Ops<float>::clamp_to_side) replace the compare and the select by
+// one v_med3_f32: TM8192 f32 7.56 -> 8.31 (form 2) / 8.07 (form 3), i8 7.11 -> 7.45 M codewords/s (same-process A/B,
+// profiles/r03_kbench/kb1.txt; identical outputs).  Form 2 is the faster one but narrows the f32 range vote
+// (nocap_limit_for): the launcher uses it while that limit leaves room for real LLRs and form 3 beyond.
+template <class T>
+constexpr int pair_form_default()
+{
+    if (LDPC_PAIR_SELFCORR_MED3 >= 0) return LDPC_PAIR_SELFCORR_MED3;
+    return (sizeof(T) > 4 || std::is_same_v<T, int32_t>) ? 0 : 2;
+}
+
+template <int CODE, class T, int FORM = pair_form_default<T>()>
 __global__ void __launch_bounds__((PairGeometry<CODE, T>::NT))
 decode_ms_pair_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters_out,
                       uint8_t *__restrict__ success_out, uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim)
@@ -487,10 +500,10 @@ decode_ms_pair_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output, 
     using GEO = PairGeometry<CODE, T>;
     __shared__ __attribute__((aligned(16))) char lds[GEO::LDS_BYTES];
     const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / (GEO::M / 8);          // quarter of this wave's indices
-    if (jw == 0) decode_ms_pair_body<CODE, T, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
-    else if (jw == 1) decode_ms_pair_body<CODE, T, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
-    else if (jw == 2) decode_ms_pair_body<CODE, T, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
-    else decode_ms_pair_body<CODE, T, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    if (jw == 0) decode_ms_pair_body<CODE, T, 0, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    else if (jw == 1) decode_ms_pair_body<CODE, T, 1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    else if (jw == 2) decode_ms_pair_body<CODE, T, 2, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
+    else decode_ms_pair_body<CODE, T, 3, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, lds);
 }
 
 }  // namespace ldpc

@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
@@ -62,6 +62,11 @@
 #ifndef LDPC_WG_VERDICT
 #define LDPC_WG_VERDICT -1
 #endif
+// register-lean kernels: in-phase verdict through a third barrier, skipping the minima / next-u half of the last check phase
+// (LEAN_VERDICT in the kernel body): -1 = per kernel (lean_verdict_default())
+#ifndef LDPC_LEAN_VERDICT
+#define LDPC_LEAN_VERDICT -1
+#endif
 // f32: clamp-free check phase for codewords whose LLRs are bounded (NOCAP_POSSIBLE in the kernel body).
 #ifndef LDPC_NOCAP
 #define LDPC_NOCAP 1
@@ -102,7 +107,8 @@
 // rest still covers the latency of the marginal reads.  f32 0/3/5/7/9/14 -> 7.04 / 7.07 / 7.24 / 7.41 /
 // 7.32 / 7.26 M codewords/s in round 1; re-swept after the multiply form of the self-correction test
 // (round 2): 5/6/7/8/9/11 -> 7.23 / 7.30 / 7.40 / 7.49 / 7.41 / 7.14; i8 3/4/5/6/7 -> 6.70 / 6.79 / 6.75 / 6.76 /
-// 6.73.  -1 = per type (8 for f32, 4 else).
+// 6.73.  Round 3, with the clamp form of the self-correction (cheaper updates): f32 6/7/8/9/10/12 -> 8.00 / 8.03 / 8.30 / 8.28 /
+// 8.33 / 8.15; i8 2/4/6/8 -> 7.43 / 7.45 / 7.35 / 7.55.  -1 = per type (10 for f32, 8 else).
 #ifndef LDPC_PAIR_LOCAL_IN_VAR
 #define LDPC_PAIR_LOCAL_IN_VAR -1
 #endif

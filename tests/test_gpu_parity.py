@@ -129,6 +129,13 @@ def test_small_maxiters(code, maxiters):
         assert (ok[-8:] == 1).all() and (it[-8:] <= 1).all()                  # punctured codes need one iteration (decoder.rs:607-645)
     l8, _ = oracle.awgn_llrs(code, rng, 32, 5.0, np.int8)
     _compare(code, l8, maxiters)
+    # the other LLR types, each after a longer decode of other frames has left its state in the LDS (the in-place f64 kernels
+    # keep marginal sign words there: round 3 found them hard-deciding the PREVIOUS codeword's at max_iters 0)
+    for dtype, scale, lim in ((np.float64, 1.0, 0), (np.int16, 64.0, 4095), (np.int32, 3e8, 2 ** 31 - 1)):
+        other, _ = oracle.awgn_llrs(code, rng, 600, 1.0, dtype, scale=scale, lim=lim)
+        code.decode_ms_batch(other, 6)
+        lx, _ = oracle.awgn_llrs(code, rng, 600, 4.0, dtype, scale=scale, lim=lim)
+        _compare(code, lx, maxiters)
 
 
 def test_ragged_batches():

@@ -4,6 +4,7 @@
 // Frames: all-zero codeword (valid for a linear code; min-sum is symmetric) + AWGN at 2 dB.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 #define LDPC_KBENCH 1          // the only place the kernels' experiment switches may be set (decode_ms_tuning.hpp)
@@ -46,12 +47,14 @@ int main()
     using namespace ldpc;
     constexpr int code = KCODE;
     const CodeInfo &ci = CODES[code];
-    const size_t F = KFRAMES, n = ci.n, ol = ci.output_len();
+    const size_t FMAX = KFRAMES, n = ci.n, ol = ci.output_len();
+    size_t F = FMAX;
+    if (const char *e = getenv("KB_F")) { F = (size_t)atoll(e); if (F < 1 || F > FMAX) F = FMAX; }   // fewer frames of the same allocation
     const float sigma = (float)std::sqrt(1.0 / (2.0 * ((double)ci.k / ci.n) * std::pow(10.0, KEBN0 / 10.0)));
     uint8_t *pool; KT *llrs; uint8_t *out, *ok; uint32_t *iters;
     CK(hipMalloc(&pool, n / 8)); CK(hipMemset(pool, 0, n / 8));
-    CK(hipMalloc(&llrs, F * n * sizeof(KT))); CK(hipMalloc(&out, F * ol)); CK(hipMalloc(&ok, F)); CK(hipMalloc(&iters, F * 4));
-    CK(launch_awgn<KT>(pool, 1, llrs, (int)n, F, sigma, 8.f, 31, 0x1DBCull + code, nullptr));
+    CK(hipMalloc(&llrs, FMAX * n * sizeof(KT))); CK(hipMalloc(&out, FMAX * ol)); CK(hipMalloc(&ok, FMAX)); CK(hipMalloc(&iters, FMAX * 4));
+    CK(launch_awgn<KT>(pool, 1, llrs, (int)n, FMAX, sigma, 8.f, 31, 0x1DBCull + code, nullptr));
     using GEO = Geometry<code, KT, KIPT>;
     unsigned groups = (unsigned)((F + GEO::G - 1) / GEO::G);
     {   // the launcher's grid (decode_ms_launch.hpp): the resident set with the queue, 16x it (where several workgroups share a CU) without
@@ -61,7 +64,11 @@ int main()
         const unsigned chunks = groups;
 #else
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>, GEO::WG, 0));
+#ifdef KSTATIC
+        const unsigned K = 1, chunks = groups;
+#else
         const unsigned K = claim_chunk<code, KT, KIPT>(), chunks = (groups + K - 1) / K;
+#endif
 #endif
         CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
         unsigned resident = (unsigned)(per_cu * cus);
@@ -73,6 +80,7 @@ int main()
 #ifdef KGRID
         grid = KGRID;
 #endif
+        if (const char *e = getenv("KB_GRID")) { if (atoi(e) > 0) grid = (unsigned)atoi(e); }
         groups = grid < chunks ? grid : chunks;
         printf("occupancy %d workgroups per CU x %d CUs; grid %u\n", per_cu, cus, groups);
     }
@@ -82,15 +90,19 @@ int main()
 #endif
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e30f;
+    int burst = 1;                                             // launches between the two events (KB_BURST): back to back, no host gap
+    if (const char *e = getenv("KB_BURST")) { burst = atoi(e); if (burst < 1) burst = 1; }
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
+        for (int bi = 0; bi < burst; ++bi)
 #if KPAIR
         hipLaunchKernelGGL((decode_ms_pair_kernel<code, KT>), dim3(groups), dim3(PairGeometry<code, KT>::NT), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim);
 #else
-        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim);
+        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim, (uint32_t)claim_chunk<code, KT, KIPT>());
 #endif
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
+        ms /= burst;
         if (rep > 0 && ms < best) best = ms;
     }
     std::vector<uint32_t> hi(F); std::vector<uint8_t> hk(F), ho(F * ol);
