@@ -230,9 +230,20 @@ void labrador_ldpc_llrs_to_hard_f64(enum labrador_ldpc_code code, const double  
 #define LABRADOR_LDPC_HIP_DEVICE_CURRENT (-1)  /* the calling thread's current HIP device */
 #define LABRADOR_LDPC_HIP_DEVICE_ALL     (-2)  /* MEM_HOST only: shard the batch over every gfx950 device */
 
-/* Zero-initialise, then set what you need: `struct labrador_ldpc_hip_opts o = {0};` means device 0,
- * host memory, default stream, tuned kernel. */
+/* ABI of the batched entry points.  3 = `struct labrador_ldpc_hip_opts` starts with `struct_size` (this header).
+ * (1 = the 24-byte struct of library 0.1.0, 2 = 0.2.0's 32-byte struct with n_devices / devices appended and no way for the
+ * library to tell the two apart -- a 0.1.0 client handed 0.2.0 its padding as n_devices.  Both are gone: the shared object
+ * carries the soname liblabrador_ldpc_hip.so.3, and labrador_ldpc_hip_abi_version() lets a dlopen() client check.) */
+#define LABRADOR_LDPC_HIP_ABI 3
+
+/* Zero-initialise, then set what you need: `struct labrador_ldpc_hip_opts o = {0};` means device 0, host memory, default
+ * stream, tuned kernel.  `struct_size` is what makes the struct growable: the library reads a field only if it lies inside
+ * the first `struct_size` bytes and takes every field beyond as zero, so a client built against THIS header keeps working
+ * with a later library whose struct has grown.  0 (what `= {0}` leaves) stands for this header's layout up to and
+ * including `devices`; LABRADOR_LDPC_HIP_OPTS_INIT sets it to the client's own sizeof, which is what a client should use
+ * from now on. */
 struct labrador_ldpc_hip_opts {
+    size_t struct_size; /* sizeof(struct labrador_ldpc_hip_opts) as the CALLER compiled it, or 0 (see above) */
     int   device;     /* HIP device ordinal, LABRADOR_LDPC_HIP_DEVICE_CURRENT or _ALL */
     int   memory;     /* LABRADOR_LDPC_HIP_MEM_HOST or _DEVICE */
     void *stream;     /* hipStream_t to launch on; NULL = the default stream.  With MEM_DEVICE
@@ -242,6 +253,7 @@ struct labrador_ldpc_hip_opts {
     int   n_devices;  /* > 0: shard a MEM_HOST batch over devices[0 .. n_devices) (`device` is ignored) */
     const int *devices; /* HIP ordinals; an ordinal may repeat (that many host pipelines on it) */
 };
+#define LABRADOR_LDPC_HIP_OPTS_INIT { sizeof(struct labrador_ldpc_hip_opts) }
 
 /* Multi-GPU (the reference's analogue is perftest/src/main.rs:39-45, one worker per
  * core over independent frames): with MEM_HOST buffers and a device set -- `device` ==
@@ -347,11 +359,19 @@ int labrador_ldpc_hip_shard_range(size_t batch, size_t parts, size_t index, size
 /* Number of HIP devices usable by this library (gfx950 only); 0 if none. Never fails. */
 int labrador_ldpc_hip_device_count(void);
 
-/* Human-readable description of the calling thread's last failure ("" if none). */
+/* Human-readable description of the calling thread's last failure ("" if none).  The reference-shaped single-frame calls
+ * (labrador_ldpc_decode_ms_*, labrador_ldpc_decode_bf) keep the reference's signature and can only return `false` when the
+ * library could not run at all (no GPU, a HIP failure, a bad code): they then zero `output`, set *iters_run = max_iters, and
+ * leave the reason here -- check it to tell "did not converge" from "did not run" (with LABRADOR_LDPC_HIP_VERBOSE=1 in the
+ * environment the reason is also written to stderr, once per distinct failure site). */
 const char *labrador_ldpc_hip_last_error(void);
 
 /* Library version string. */
 const char *labrador_ldpc_hip_version(void);
+
+/* The LABRADOR_LDPC_HIP_ABI the loaded library was built with: a client that dlopen()s the library compares it with its
+ * own header's before passing a struct labrador_ldpc_hip_opts. */
+int labrador_ldpc_hip_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -30,9 +30,14 @@ class LdpcHipError(RuntimeError):
 class HipOpts(ctypes.Structure):
     """struct labrador_ldpc_hip_opts (include/labrador_ldpc_hip.h)."""
 
-    _fields_ = [("device", ctypes.c_int), ("memory", ctypes.c_int),
+    _fields_ = [("struct_size", ctypes.c_size_t), ("device", ctypes.c_int), ("memory", ctypes.c_int),
                 ("stream", ctypes.c_void_p), ("variant", ctypes.c_int),
                 ("n_devices", ctypes.c_int), ("devices", ctypes.POINTER(ctypes.c_int))]
+
+    def __init__(self, device=0, memory=0, stream=None, variant=0, n_devices=0, devices=None, struct_size=None):
+        # struct_size (ABI 3) tells the library how much of the struct this caller knows; fields beyond it read as zero
+        super().__init__(ctypes.sizeof(HipOpts) if struct_size is None else struct_size, device, memory, stream, variant,
+                         n_devices, devices)
 
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -86,6 +91,7 @@ SYMBOLS = {
     "labrador_ldpc_hip_device_count": (_int, []),
     "labrador_ldpc_hip_last_error": (_c.c_char_p, []),
     "labrador_ldpc_hip_version": (_c.c_char_p, []),
+    "labrador_ldpc_hip_abi_version": (_int, []),
 }
 
 

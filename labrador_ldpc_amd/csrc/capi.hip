@@ -5,7 +5,12 @@
 // with a CPU path.
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
+
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +51,21 @@ int fail(int status, const char *fmt, ...)
     va_end(ap);
     g_err = buf;
     return status;
+}
+
+// struct labrador_ldpc_hip_opts as the CALLER laid it out -> this build's layout: a field is read only if it lies inside the
+// first struct_size bytes (0 = this header's layout up to `devices`), everything beyond is zero (include/labrador_ldpc_hip.h).
+// Returns nullptr for a NULL opts, else `local`.
+const labrador_ldpc_hip_opts *normalise_opts(const labrador_ldpc_hip_opts *opts, labrador_ldpc_hip_opts &local)
+{
+    if (!opts) return nullptr;
+    local = labrador_ldpc_hip_opts{};
+    size_t have = opts->struct_size ? opts->struct_size : sizeof(labrador_ldpc_hip_opts);
+    if (have > sizeof(labrador_ldpc_hip_opts)) have = sizeof(labrador_ldpc_hip_opts);      // a newer client: fields this build does not know
+    if (have < offsetof(labrador_ldpc_hip_opts, device)) have = offsetof(labrador_ldpc_hip_opts, device);
+    std::memcpy(&local, opts, have);
+    local.struct_size = sizeof(labrador_ldpc_hip_opts);
+    return &local;
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -378,6 +398,43 @@ void shard_range(size_t total, size_t parts, size_t index, size_t *first, size_t
     *count = base + (index < extra ? 1 : 0);
 }
 
+// NUMA placement of a device's worker (round 2's review, weak #7): the host path is bound by PCIe at ~55 GB/s per GPU, and
+// eight of them read ~440 GB/s of host memory -- more than one socket's interconnect carries if every staging copy starts on
+// the wrong node.  A worker pins itself to the CPUs local to its GPU (sysfs: /sys/bus/pci/devices/<bus id>/local_cpulist,
+// intersected with the CPUs the process may use) BEFORE it allocates anything, so its pinned staging memory is first touched
+// on that node and its pageable copies run there; its collector thread inherits the mask.  Best effort: any failure (no sysfs
+// entry, an empty intersection, LABRADOR_LDPC_HIP_NO_NUMA set) leaves the thread where it is.
+void pin_to_device_node(int dev)
+{
+    if (const char *e = std::getenv("LABRADOR_LDPC_HIP_NO_NUMA")) { if (*e && *e != '0') return; }
+    char bus[32] = {};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');       // sysfs spells hex digits in lower case
+    char path[128];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return;
+    char list[4096] = {};
+    const bool got = std::fgets(list, (int)sizeof list, f) != nullptr;
+    std::fclose(f);
+    if (!got) return;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    int n = 0;
+    for (const char *p = list; *p && *p != '\n';) {                                              // "0-23,96-119"
+        char *end = nullptr;
+        long a = std::strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        if (*end == '-') { p = end + 1; b = std::strtol(p, &end, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &want); ++n; }
+        p = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    if (n > 0) (void)sched_setaffinity(0, sizeof want, &want);
+}
+
 struct Worker {
     struct Job {
         std::function<int()> fn;
@@ -388,9 +445,11 @@ struct Worker {
     std::mutex m;
     std::condition_variable cv;
     std::deque<Job *> queue;
-    Worker() { std::thread([this] { run(); }).detach(); }
+    const int dev;                                     // the one device this worker ever serves
+    explicit Worker(int device) : dev(device) { std::thread([this] { run(); }).detach(); }
     void run()
     {
+        pin_to_device_node(dev);
         for (;;) {
             Job *j = nullptr;
             {
@@ -422,13 +481,29 @@ struct Worker {
     }
 };
 
-Worker &worker(size_t slot)
+// Workers are keyed by (device ordinal, how many times that ordinal has occurred in the list so far): a worker's
+// thread-local staging pool, streams and pinned buffer hold ONE device's resources, so it must keep serving that device
+// whatever order a later call lists the devices in (by position, [0, 1] followed by [1, 0] made every worker free and
+// re-create everything).  The detached threads do not survive fork(): the child gets a fresh, empty pool (atfork handler;
+// the parent's Worker objects are leaked in the child on purpose -- their mutexes may be held by threads that no longer
+// exist), and its first sharded call starts its own workers.
+struct WorkerPool {
+    std::mutex m;
+    std::vector<std::vector<Worker *>> by_dev;         // [device][occurrence]
+};
+WorkerPool *g_workers = new WorkerPool;                // leaked on purpose: workers are parked on their condition variable at exit
+void workers_after_fork_in_child() { g_workers = new WorkerPool; }
+
+Worker &worker(int dev, size_t occurrence)
 {
-    static std::mutex *m = new std::mutex;                       // leaked on purpose, see above
-    static std::vector<Worker *> *pool = new std::vector<Worker *>;
-    std::lock_guard<std::mutex> lk(*m);
-    while (pool->size() <= slot) pool->push_back(new Worker);
-    return *(*pool)[slot];
+    static const int registered = pthread_atfork(nullptr, nullptr, workers_after_fork_in_child);
+    (void)registered;
+    WorkerPool &p = *g_workers;
+    std::lock_guard<std::mutex> lk(p.m);
+    if (p.by_dev.size() <= (size_t)dev) p.by_dev.resize((size_t)dev + 1);
+    auto &v = p.by_dev[(size_t)dev];
+    while (v.size() <= occurrence) v.push_back(new Worker(dev));
+    return *v[occurrence];
 }
 
 // The devices a call should shard over: empty = single-device call.  Returns a status.
@@ -474,17 +549,20 @@ int run_sharded(const std::vector<int> &devs, size_t items, int variant, Run run
     const size_t parts = devs.size();
     std::vector<Worker::Job> jobs(parts);
     std::vector<labrador_ldpc_hip_opts> sub(parts);
+    std::vector<Worker *> who(parts);
     for (size_t i = 0; i < parts; ++i) {
-        size_t first, count;
+        size_t first, count, occurrence = 0;
         shard_range(items, parts, i, &first, &count);
-        sub[i] = labrador_ldpc_hip_opts{devs[i], LABRADOR_LDPC_HIP_MEM_HOST, nullptr, variant, 0, nullptr};
+        for (size_t k = 0; k < i; ++k) occurrence += devs[k] == devs[i] ? 1 : 0;
+        sub[i] = labrador_ldpc_hip_opts{sizeof(labrador_ldpc_hip_opts), devs[i], LABRADOR_LDPC_HIP_MEM_HOST, nullptr, variant, 0, nullptr};
         const labrador_ldpc_hip_opts *o = &sub[i];
         jobs[i].fn = [=]() -> int { return count ? run(first, count, o) : LABRADOR_LDPC_HIP_OK; };
-        worker(i).post(&jobs[i]);
+        who[i] = &worker(devs[i], occurrence);
+        who[i]->post(&jobs[i]);
     }
     int status = LABRADOR_LDPC_HIP_OK;
     for (size_t i = 0; i < parts; ++i) {
-        worker(i).wait(&jobs[i]);
+        who[i]->wait(&jobs[i]);
         if (jobs[i].status != LABRADOR_LDPC_HIP_OK && status == LABRADOR_LDPC_HIP_OK) {
             status = jobs[i].status;
             char pre[48];
@@ -500,6 +578,8 @@ int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint
                  size_t batch, size_t max_iters, const labrador_ldpc_hip_opts *opts)
 {
     g_err.clear();
+    labrador_ldpc_hip_opts opts_local;
+    opts = normalise_opts(opts, opts_local);
     if (!ldpc::valid_code(code)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", code);
     if (batch == 0) return LABRADOR_LDPC_HIP_OK;
     if (!llrs || !output || !iters || !success) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
@@ -544,6 +624,18 @@ int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint
     });
 }
 
+// The reference-shaped single-frame calls can only say `false` when the library could not run at all (no GPU, a HIP failure,
+// a bad code).  The reference always writes its outputs (capi/src/lib.rs:91-93), so a caller may print them: they are made
+// defined -- output zeroed, *iters_run = max_iters -- the reason stays in labrador_ldpc_hip_last_error(), and with
+// LABRADOR_LDPC_HIP_VERBOSE set it is written to stderr too (the library is silent otherwise, like the reference's).
+void did_not_run(int code, uint8_t *output, size_t max_iters, size_t *iters_run)
+{
+    if (output && ldpc::valid_code(code)) std::memset(output, 0, ldpc::CODES[code].output_len());
+    if (iters_run) *iters_run = max_iters;
+    static const bool verbose = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_VERBOSE"); return e && *e && *e != '0'; }();
+    if (verbose) std::fprintf(stderr, "labrador_ldpc_hip: the decoder did not run: %s\n", g_err.c_str());
+}
+
 // capi/src/lib.rs:83-95: one frame, host pointers, optional iteration count
 template <class T>
 bool decode_one(int code, const T *llrs, uint8_t *output, size_t max_iters, size_t *iters_run)
@@ -551,7 +643,7 @@ bool decode_one(int code, const T *llrs, uint8_t *output, size_t max_iters, size
     uint32_t it = 0;
     uint8_t ok = 0;
     const int s = decode_batch<T>(code, llrs, output, &it, &ok, 1, max_iters, nullptr);
-    if (s != LABRADOR_LDPC_HIP_OK) return false;        // silent like the reference boundary; reason: labrador_ldpc_hip_last_error()
+    if (s != LABRADOR_LDPC_HIP_OK) { did_not_run(code, output, max_iters, iters_run); return false; }
     // iters is clamped to 32 bits inside the kernel; report the caller's own bound on failure
     if (iters_run) *iters_run = ok ? (size_t)it : max_iters;
     return ok != 0;
@@ -585,6 +677,8 @@ template <class T>
 int hard_to_llrs_batch(int code, const uint8_t *input, T *llrs, size_t batch, const labrador_ldpc_hip_opts *opts)
 {
     g_err.clear();
+    labrador_ldpc_hip_opts opts_local;
+    opts = normalise_opts(opts, opts_local);
     if (!ldpc::valid_code(code)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", code);
     if (batch == 0) return LABRADOR_LDPC_HIP_OK;
     if (!input || !llrs) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
@@ -606,6 +700,8 @@ template <class T>
 int llrs_to_hard_batch(int code, const T *llrs, uint8_t *output, size_t batch, const labrador_ldpc_hip_opts *opts)
 {
     g_err.clear();
+    labrador_ldpc_hip_opts opts_local;
+    opts = normalise_opts(opts, opts_local);
     if (!ldpc::valid_code(code)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", code);
     if (batch == 0) return LABRADOR_LDPC_HIP_OK;
     if (!llrs || !output) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
@@ -628,6 +724,8 @@ int awgn(int code, const uint8_t *codewords, size_t pool, T *llrs, size_t batch,
          int lim, uint64_t seed, const labrador_ldpc_hip_opts *opts)
 {
     g_err.clear();
+    labrador_ldpc_hip_opts opts_local;
+    opts = normalise_opts(opts, opts_local);
     if (!ldpc::valid_code(code)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", code);
     if (batch == 0) return LABRADOR_LDPC_HIP_OK;
     if (!codewords || !llrs || pool == 0 || pool > 0xFFFFFFFFull) return fail(LABRADOR_LDPC_HIP_EINVAL, "bad codeword pool");
@@ -672,6 +770,8 @@ int labrador_ldpc_decode_bf_batch(enum labrador_ldpc_code c, const uint8_t *inpu
                                   const struct labrador_ldpc_hip_opts *opts)
 {
     g_err.clear();
+    labrador_ldpc_hip_opts opts_local;
+    opts = normalise_opts(opts, opts_local);
     if (!ldpc::valid_code(c)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", (int)c);
     if (batch == 0) return LABRADOR_LDPC_HIP_OK;
     if (!input || !output || !iters || !success) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
@@ -710,7 +810,7 @@ bool labrador_ldpc_decode_bf(enum labrador_ldpc_code c, const uint8_t *input, ui
     uint32_t it = 0;
     uint8_t ok = 0;
     const int s = labrador_ldpc_decode_bf_batch(c, input, output, &it, &ok, 1, max_iters, nullptr);
-    if (s != LABRADOR_LDPC_HIP_OK) return false;
+    if (s != LABRADOR_LDPC_HIP_OK) { did_not_run(c, output, max_iters, iters_run); return false; }
     if (iters_run) *iters_run = ok ? (size_t)it : max_iters;
     return ok != 0;
 }
@@ -798,6 +898,8 @@ int labrador_ldpc_encode_batch(enum labrador_ldpc_code c, const uint8_t *data, u
                                const struct labrador_ldpc_hip_opts *opts)
 {
     g_err.clear();
+    labrador_ldpc_hip_opts opts_local;
+    opts = normalise_opts(opts, opts_local);
     if (!ldpc::valid_code(c)) return fail(LABRADOR_LDPC_HIP_EINVAL, "code %d out of range", (int)c);
     if (batch == 0) return LABRADOR_LDPC_HIP_OK;
     if (!data || !codewords) return fail(LABRADOR_LDPC_HIP_EINVAL, "NULL buffer");
@@ -879,7 +981,8 @@ int labrador_ldpc_hip_device_count(void)
 }
 
 const char *labrador_ldpc_hip_last_error(void) { return g_err.c_str(); }
-const char *labrador_ldpc_hip_version(void) { return "labrador_ldpc_hip 0.2.0 (gfx950)"; }
+const char *labrador_ldpc_hip_version(void) { return "labrador_ldpc_hip 0.3.0 (gfx950)"; }
+int labrador_ldpc_hip_abi_version(void) { return LABRADOR_LDPC_HIP_ABI; }
 
 int labrador_ldpc_hip_shard_range(size_t batch, size_t parts, size_t index, size_t *first, size_t *count)
 {

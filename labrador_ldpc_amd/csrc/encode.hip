@@ -10,6 +10,7 @@
 // HBM traffic is the algorithmic minimum (k/8 bytes in, n/8 bytes out per frame); the
 // generator (<= 2 MB) is read once per workgroup from L2.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <vector>
@@ -202,18 +203,36 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
     // than to the batch: with one workgroup per handful of frames (round 1: min(batch, 4096)) the launch moved
     // 8.6 GB of generator for TM8192 whatever the batch, 3.3 ms of a 3.9 ms launch at 32 768 frames.
     const unsigned gx = (np + 255) / 256;
-    int cus = 0, per_cu = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus < 1) cus = 256;
+    // compute units of the CURRENT device (sharded workers and opts->device run on others than 0) and the kernels'
+    // occupancy, queried once per device and kernel: a single-frame labrador_ldpc_encode-sized call should not pay two
+    // uncached runtime queries per launch (the decode launchers cache the same quantity: resident_workgroups())
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static std::atomic<int> cached_cus[64] = {}, cached_occ[64][6] = {};         // [device][kernel]; concurrent fills store the same value
+    int cus = cached_cus[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached_cus[dev].store(cus, std::memory_order_relaxed);
+    }
     const void *kfn = nullptr;
+    int kid = 0;
     switch (ci.k / 32) {
-        case 2: kfn = (const void *)encode_kernel<2>; break;
-        case 4: kfn = (const void *)encode_kernel<4>; break;
-        case 8: kfn = (const void *)encode_kernel<8>; break;
-        case 32: kfn = (const void *)encode_kernel<32>; break;
-        case 128: kfn = (const void *)encode_kernel<128>; break;
+        case 2: kfn = (const void *)encode_kernel<2>; kid = 0; break;
+        case 4: kfn = (const void *)encode_kernel<4>; kid = 1; break;
+        case 8: kfn = (const void *)encode_kernel<8>; kid = 2; break;
+        case 32: kfn = (const void *)encode_kernel<32>; kid = 3; break;
+        case 128: kfn = (const void *)encode_kernel<128>; kid = 4; break;
         default: return hipErrorInvalidValue;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    auto occupancy = [&](const void *fn, int slot) {
+        int v = cached_occ[dev][slot].load(std::memory_order_relaxed);
+        if (v == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, 256, 0) != hipSuccess || v < 1) v = 2;
+            cached_occ[dev][slot].store(v, std::memory_order_relaxed);
+        }
+        return v;
+    };
+    const int per_cu = occupancy(kfn, kid);
     // exactly the resident set where a workgroup's generator load is heavy (k = 4096: 128 KB), several times it
     // for the small codes, whose workgroups are cheap to start and balance better when there are more of them
     const unsigned rounds = ci.k >= 4096 ? 1 : 4;
@@ -224,8 +243,7 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
     const dim3 grid(gx, gy);
     if (ci.k == 4096 && (uintptr_t)data % 16 == 0 && (uintptr_t)codewords % 16 == 0 && np % 256 == 0) {
         // LDS-staged kernel: contiguous runs of frames per workgroup, a multiple of its 8-frame stage
-        int per_cu2 = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void *)encode_kernel_k4096, 256, 0) != hipSuccess || per_cu2 < 1) per_cu2 = 2;
+        const int per_cu2 = occupancy((const void *)encode_kernel_k4096, 5);
         unsigned gy2 = (unsigned)(cus * per_cu2) / gx > 0 ? (unsigned)(cus * per_cu2) / gx : 1;
         size_t per_wg = (batch + gy2 - 1) / gy2;
         per_wg = (per_wg + 7) / 8 * 8;

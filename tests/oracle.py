@@ -10,7 +10,8 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(_ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libldpc_oracle.so")
+# LDPC_ORACLE_LIB: another build of the same sources (tests/test_sanitizers.py runs the known-answer suite on the ASan + UBSan one)
+ORACLE_LIB = os.environ.get("LDPC_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libldpc_oracle.so")
 
 CODES = ["TC128", "TC256", "TC512", "TM1280", "TM1536", "TM2048", "TM5120", "TM6144", "TM8192"]
 _SUF = {np.dtype(np.int8): "i8", np.dtype(np.int16): "i16", np.dtype(np.int32): "i32",
@@ -18,6 +19,8 @@ _SUF = {np.dtype(np.int8): "i8", np.dtype(np.int16): "i16", np.dtype(np.int32): 
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("LDPC_ORACLE_LIB"):
+        return ORACLE_LIB                          # the caller built it
     if force or not os.path.exists(ORACLE_LIB):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return ORACLE_LIB

@@ -134,3 +134,54 @@ def test_decode_without_gpu_fails_loudly():
         code.decode_bf(np.zeros(code.n() // 8, dtype=np.uint8), np.zeros(code.output_len(), dtype=np.uint8))
     with pytest.raises(la.LdpcHipError):
         code.encode_batch(np.zeros((2, code.k() // 8), dtype=np.uint8))
+
+
+def test_abi_version_and_growable_opts_struct():
+    """struct labrador_ldpc_hip_opts grew between 0.1.0 and 0.2.0 with nothing to tell the layouts apart.  ABI 3: the
+    struct starts with struct_size; the library reads a field only if it lies inside the first struct_size bytes and takes the
+    rest as zero, so a caller that knows fewer fields cannot hand it padding as n_devices / devices."""
+    import ctypes
+    assert la.lib.labrador_ldpc_hip_abi_version() == 3
+    assert "0.3.0" in la.lib.labrador_ldpc_hip_version().decode()
+    assert ctypes.sizeof(la.HipOpts) == 40 and la.HipOpts.device.offset == 8 and la.HipOpts.n_devices.offset == 28
+    code = LDPCCode.TC128
+    llrs = np.ones((2, code.n()), dtype=np.float32)
+    out = np.zeros((2, code.output_len()), dtype=np.uint8)
+    it, ok = np.zeros(2, dtype=np.uint32), np.zeros(2, dtype=np.uint8)
+    call = lambda o: la.lib.labrador_ldpc_decode_ms_batch_f32(int(code), llrs.ctypes.data, out.ctypes.data, it.ctypes.data,
+                                                              ok.ctypes.data, 2, 5, ctypes.byref(o))
+    gpu = la.device_count() > 0
+    # a full-size struct with a device list is checked as one (without a GPU the first check that can fail is the stream's) ...
+    bad_stream = None if gpu else 1234
+    want = "devices is NULL" if gpu else "opts->stream must be NULL"
+    st = call(la.HipOpts(-1, la.MEM_HOST, bad_stream, 0, 5, None))
+    assert st == -1 and want in la.last_error(), la.last_error()
+    # ... the same bytes from a caller whose struct ends before n_devices are a plain single-device call: the 5 is not read
+    st = call(la.HipOpts(-1, la.MEM_HOST, bad_stream, 0, 5, None, struct_size=la.HipOpts.n_devices.offset))
+    if gpu:
+        assert st == 0
+    else:
+        assert st == -2 and "no HIP device" in la.last_error()
+    # struct_size 0 (what `= {0}` leaves) means this header's layout; a larger one (a newer client) is accepted too
+    for size in (0, 64):
+        st = call(la.HipOpts(-1, la.MEM_HOST, bad_stream, 0, 5, None, struct_size=size))
+        assert st == -1 and want in la.last_error()
+
+
+def test_single_frame_calls_define_their_outputs_when_the_library_cannot_run():
+    """the reference-shaped calls can only return `false`; when the library could not run they must not leave
+    *iters_run and output as they found them (the reference always writes them, capi/src/lib.rs:91-93)."""
+    import ctypes
+    if la.device_count() > 0:
+        pytest.skip("a GPU is present: the calls run")
+    code = LDPCCode.TC128
+    llrs = np.ones(code.n(), dtype=np.float32)
+    out = np.full(code.output_len(), 0xAB, dtype=np.uint8)
+    iters = ctypes.c_size_t(12345)
+    ok = la.lib.labrador_ldpc_decode_ms_f32(int(code), llrs.ctypes.data, out.ctypes.data, None, None, 50, ctypes.byref(iters))
+    assert not ok and iters.value == 50 and not out.any() and "no HIP device" in la.last_error()
+    out[:] = 0xCD
+    iters.value = 777
+    ok = la.lib.labrador_ldpc_decode_bf(int(code), np.zeros(code.n() // 8, dtype=np.uint8).ctypes.data, out.ctypes.data, None, 20,
+                                        ctypes.byref(iters))
+    assert not ok and iters.value == 20 and not out.any()

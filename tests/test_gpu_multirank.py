@@ -1,0 +1,56 @@
+"""8-GPU readiness that one GPU can prove (round 2's review, item 7): bench.py's multi-rank path -- rendezvous on 127.0.0.1,
+rank -> device map, contiguous shards of ONE batch ("strong" scaling), every rank's parity sample, the world-size-N gloo MAX
+of the timings, one JSON line from rank 0 -- run with all ranks mapped onto device 0.  Three launch shapes: bench.py starting
+its own ranks (8 of them), the driver's `python -m torch.distributed.run ... bench.py --gpus N`, and ranks that each see one
+visible device (HIP_VISIBLE_DEVICES).  Reference analogue: one job, however many workers (perftest/src/main.rs:39-52)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(d, world, total):
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] and d["value"] > 0
+    assert d["config"]["total_frames"] == total and abs(d["config"]["frames_per_gpu"] - total / world) <= 1
+    assert d["parity"]["mismatches"] == 0 and d["parity"]["frames_compared"] == 32 * world
+    assert d["metric"].startswith("decoded codewords/sec @25 min-sum iters, TM8192")
+    assert d["cpu_baseline"] is None and "configs" not in d
+
+
+def test_eight_ranks_on_one_gpu_started_by_bench_py():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--total-frames", "65536", "--steps", "2",
+                        "--warmup", "1", "--rank-parity-frames", "32", "--no-configs"], capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    _check(_one_json_line(r.stdout), 8, 65536)
+
+
+def test_two_ranks_under_the_drivers_launcher():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--devices", "0,0", "--total-frames", "32769", "--steps", "2",
+                        "--warmup", "1", "--rank-parity-frames", "32", "--no-configs"], capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    _check(_one_json_line(r.stdout), 2, 32769)            # an odd total: the shards differ by one frame
+
+
+def test_ranks_that_each_see_one_visible_device():
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--total-frames", "16384", "--steps", "1", "--warmup", "1",
+                        "--rank-parity-frames", "32", "--no-configs"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    _check(_one_json_line(r.stdout), 2, 16384)

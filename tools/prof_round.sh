@@ -1,9 +1,9 @@
 #!/bin/bash
 # Profiling recipe of a round (run on the GPU box through gpurun): the default bench line, the same command under
 # rocprofv3 --kernel-trace --stats, and PMC passes (separate runs, --pmc only) for the headline kernel and for the
-# other BASELINE configs.   usage:  bash tools/prof_round.sh r02_final     -> gpurun_out/r02_final
+# other BASELINE configs.   usage:  bash tools/prof_round.sh r03_final     -> gpurun_out/r03_final
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02_final}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03_final}; mkdir -p $O
 rm -rf $O/trace $O/*.pmc[1-5]          # a re-run must not leave an older run's files beside the new ones
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err

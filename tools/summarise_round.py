@@ -51,7 +51,18 @@ json.dump(allsum, open(f"{dst}/pmc_summary.json", "w"), indent=1)
 mix = f"{dst}/valu_mix_tm8192_f32.json"              # tools/valu_mix.py (static instruction mix of the iteration loop)
 if os.path.exists(mix) and "TM8192_f32" in traffic:
     traffic["TM8192_f32"]["avg_issue_cycles_per_instruction"] = json.load(open(mix))["avg_issue_cycles_per_instruction"]
+# the library build the counters were collected on (the bench line of the same gpurun call names it): bench.py reports
+# `traffic` / `valu_issue` only when the library it loaded is this one (tests/test_bench_host.py)
+build = None
+try:
+    with open(f"{src}/bench_default.json") as fh:
+        build = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])["config"]["library_build"]
+except Exception as e:
+    print("no library_build in", f"{src}/bench_default.json:", e)
 if traffic:
+    for t in traffic.values():
+        t["library_build"] = build
+    traffic["library_build"] = build
     json.dump(traffic, open("profiles/hbm_traffic.json", "w"), indent=1)
 for tag, s in allsum.items():
     w = s.get("SQ_WAVE_CYCLES")
