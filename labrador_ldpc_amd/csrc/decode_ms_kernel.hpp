@@ -261,21 +261,32 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
         const int t = __builtin_amdgcn_bitop3_b32(__float_as_int(old), __float_as_int(nv), (int)0x80000000, 0x78);
         return __int_as_float(t) < 0.0f;
     }
-    // Self-correction as a CLAMP (FORM 2 / 3).  "Keep nv iff it lies on old's side of zero (any side if old == 0)" is
+    // Self-correction as a CLAMP (FORM 2 / 3 / 5).  "Keep nv iff it lies on old's side of zero (any side if old == 0)" is
     // v = median(nv, 0, X) for any X with X = nv when old == 0 and, when old != 0, the sign of old and |X| >= |nv|.
-    //   FORM 2:  X = nv + old * big   (v_mov + v_fmac_f32, both F class) -- needs big * |old| > |nv| for every nonzero
-    //            old and every nv of the decode, which the caller guarantees (integer messages: big = 2^20; f32: the
-    //            tightened range vote, nocap_limit_for());
+    //   FORM 2:  X = fma(old, big, nv)   (one v_fma_f32: full rate on gfx950, tools/ubench/valu_rate.hip) -- needs
+    //            big * |old| > |nv| for every nonzero old and every nv of the decode, which the caller guarantees (integer
+    //            messages: big = 2^20; f32: the tightened range vote, nocap_limit_for());
     //   FORM 3:  X = nv + mul_legacy(old, inf): +-inf for every nonzero old (denormals included), 0 * inf = 0 under
-    //            the legacy rule, so no range condition beyond "nothing is NaN or infinite".
-    // One v_med3_f32 replaces the compare and the select: sub, [mov,] fmac, med3 instead of sub, mul, cmp, cndmask.
+    //            the legacy rule, so no range condition beyond "nothing is NaN or infinite";
+    //   FORM 5:  the same decision without a median: three full-rate operations, none of the 4-cycle class.
+    // One v_med3_f32 replaces the compare and the select of forms 0 / 1, and with them the VCC round trip between the two
+    // (two wait states on gfx950): sub, fma, med3 instead of sub, mul, cmp, cndmask.  Per edge update 0.94 ns against
+    // 1.13-1.25 ns per instruction slot in the micro-benchmark (profiles/r03_final/valu_rate.txt).
     template <int FORM>
     LDPC_DEV static R clamp_to_side(R nv, R old, float big)
     {
         R x, r;
         if constexpr (FORM == 2) {
-            x = nv;
-            asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "s"(big), "v"(old));
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "s"(big), "v"(old), "v"(nv));
+        } else if constexpr (FORM == 5) {
+            // No C-class instruction at all: s = clamp01(1 + nv * old * 2^100) is 1 unless the signs differ (then nv * old
+            // < 0, at least 2^-86 in magnitude for values >= 2^-43, and 1 - 2^14 clamps to 0); v = nv * s + 0 (the + 0 keeps
+            // a dropped negative nv from becoming -0.0).  Needs only "no product underflows", like the multiply form.
+            float pr, sel;
+            asm("v_mul_f32_e32 %0, %1, %2" : "=v"(pr) : "v"(nv), "v"(old));
+            asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(sel) : "v"(pr), "s"(0x1p100f));
+            asm("v_fma_f32 %0, %1, %2, 0" : "=v"(r) : "v"(nv), "v"(sel));
+            return r;
         } else {
             asm("v_mul_legacy_f32_e64 %0, %1, %2" : "=v"(x) : "v"(old), "s"(__builtin_inff()));
             x = x + nv;
@@ -581,22 +592,38 @@ constexpr int selfcorr_carry_default()
     return (CODE == TM1280 || CODE == TM1536 || CODE == TM5120) ? 2 : 0;
 }
 
-// Self-correction as a clamp (Ops<float>::clamp_to_side) in decode_ms_kernel: 0 = no, 2 = v_fmac form, 3 = v_mul_legacy form
-// (the pair kernel has a template parameter for it).  Also read by the launcher: with form 2 an f32 kernel's range vote needs
-// the tighter limit of nocap_limit_for().
-// Same-process A/B (tools/kbench.hip, profiles/r03_kbench/kb1.txt, kb2.txt; identical outputs), M codewords/s:
-//   i8, form 2: TM6144 11.65 -> 11.94, TC512 (3 dB) 312.5 -> 318.4, TM2048 46.90 -> 47.09 (form 3: 47.26), TM1536 61.79 -> 61.96;
-//   the register-lean kernels lose: TM5120 i8 19.07 -> 18.86 (4 dB), 7.34 -> 7.23 (2 dB), TM1280 i8 73.25 -> 72.75;
-//   f32 (only in a clamp-free copy of the loop): TM2048 form 3 37.07 -> 37.52, form 2 37.19; TC512 (with the loop) 130.9 -> 137.0.
+template <int CODE, int IPT>
+constexpr int Geometry_G() { return CODES[CODE].m / IPT >= 64 ? 1 : 64 / (CODES[CODE].m / IPT); }      // codewords per workgroup (Geometry::G)
+
+// Form of the self-correction in decode_ms_kernel (Ops<float>::clamp_to_side): 0 = compare / borrow + select, 2 = v_fma +
+// v_med3, 3 = v_mul_legacy + v_add + v_med3, 5 = three full-rate operations and no median.  This is the DEFAULT of the
+// kernel's FORM template parameter; for the f32 kernels with a clamp-free loop the launcher instantiates 2 and 3 and picks by
+// max_iters (form 2 narrows the range vote: nocap_limit_for()).
+// Same-process A/B (tools/kbench.hip, profiles/r03_kbench/kb11_forms.txt; identical outputs), M codewords/s, forms 0 / 2 / 3 / 5:
+//   TM6144 i8 11.63 / 12.26 / - / 12.13;  TM2048 i8 46.9 / 49.37 / 47.74 / 48.26;  TC512 i8 (3 dB) 312.5 / 318.4 / - / -;
+//   the register-lean kernels (form 0 = the borrow form there): TM5120 i8 4 dB 20.76 / 20.74 / - / 21.08, 2 dB 7.87 / 7.85 / - /
+//   7.98; TM1280 i8 77.96 / - / - / 81.44 -- their chunked check rows like the all-full-rate form best;
+//   f32 (only inside a clamp-free copy of the loop): TM2048 - / 40.29 / 38.23 / 38.19;  TC512 - / 139.96 / 136.63 / 136.80.
 template <int CODE, class T>
 constexpr int selfcorr_med3()
 {
     if (sizeof(T) > 4 || std::is_same_v<T, int32_t>) return 0;
     if (LDPC_SELFCORR_MED3 >= 0) return LDPC_SELFCORR_MED3;
     constexpr bool narrow = sizeof(T) <= 2;
-    if (CODE == TM5120 || (CODE == TM1280 && narrow)) return 0;       // the register-lean kernels (launch_one)
-    if (narrow) return CODE == TM2048 ? 3 : 2;
-    return (CODE == TM2048 || CODE == TC512) ? 3 : 0;                  // f32: the kernels with a clamp-free loop (NOCAP_POSSIBLE)
+    if (narrow) return (CODE == TM5120 || CODE == TM1280) ? 5 : 2;      // (TM5120, TM1280: the register-lean kernels, launch_one)
+    return (CODE == TM2048 || CODE == TC512) ? 2 : 0;                  // f32: the kernels with a clamp-free loop (has_nocap_loop)
+}
+
+// f32 kernels that carry a second, clamp-free copy of their iteration loop (NOCAP_POSSIBLE in the kernel body)
+template <int CODE, class T, int IPT, int LEAN>
+constexpr bool has_nocap_loop()
+{
+#ifdef LDPC_NOCAP_ALSO
+    constexpr bool code = CODE == TM2048 || CODE == TC512 || CODE == LDPC_NOCAP_ALSO;     // (kbench experiment)
+#else
+    constexpr bool code = CODE == TM2048 || CODE == TC512;
+#endif
+    return LDPC_NOCAP != 0 && std::is_same_v<T, float> && code && Geometry_G<CODE, IPT>() == 1 && LEAN == 0 && IPT == 1;
 }
 
 // The in-phase verdict of the register-lean kernels (LEAN_VERDICT in the kernel body).  Measured and refuted in round 3
@@ -688,7 +715,7 @@ LDPC_DEV int pi_dev(int i, int j)
 // JW >= 0: the body is specialised for waves whose indices start in quarter JW (the kernel
 // branches once, wave-uniformly, into the matching copy) so that every rotation constant of the
 // pi_k blocks is a literal; JW < 0: generic body, constants in SGPRs.
-template <int CODE, class T, int IPT, bool PF, int LEAN, int JW>
+template <int CODE, class T, int IPT, bool PF, int LEAN, int JW, int FORM>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                              uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k, char *lds, char *stage)
@@ -762,14 +789,9 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // with two indices per thread (the second copy of the loop is not free); TC512: 19 spilled VGPRs at the four-waves budget,
     // 108 -> 100 M codewords/s on config 2.  Hence TM2048 only.
     // (TC512: refused in round 2, when its kernel was capped at 128 registers and the second loop spilled; at today's 139 it
-    // does not, and with the clamp form of the self-correction the clamp-free loop is worth +4.6 % at 1 048 576 frames, +2.4 %
-    // on config 2's 65 536: 130.9 -> 137.0, 118.7 -> 121.6 M codewords/s, profiles/r03_kbench/kb4.txt)
-#ifdef LDPC_NOCAP_ALSO
-    constexpr bool NOCAP_CODE = CODE == TM2048 || CODE == TC512 || CODE == LDPC_NOCAP_ALSO;     // (kbench experiment)
-#else
-    constexpr bool NOCAP_CODE = CODE == TM2048 || CODE == TC512;
-#endif
-    constexpr bool NOCAP_POSSIBLE = LDPC_NOCAP && std::is_same_v<T, float> && NOCAP_CODE && G == 1 && LEAN == 0 && IPT == 1;
+    // does not, and with the clamp form of the self-correction the clamp-free loop is worth +7 % at 1 048 576 frames:
+    // 130.9 -> 140.0 M codewords/s, profiles/r03_kbench/kb4.txt, kb11_forms.txt)
+    constexpr bool NOCAP_POSSIBLE = has_nocap_loop<CODE, T, IPT, LEAN>() && G == 1;
     auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(gbase + FLAG_OFF + 8); };
 
     // Byte offset, inside one block's M*SZ-byte LDS region, of the variable that check
@@ -952,7 +974,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr bool CARRY = CARRY_SET == 2 || (CARRY_SET == 1 && !std::is_same_v<T, float>);
     // form of the self-correction (Ops::self_correct): the clamp forms where the values allow them -- integer messages
     // always, f32 only in the clamp-free copy of the loop (its codewords passed the range vote)
-    constexpr int MED3 = selfcorr_med3<CODE, T>();
+    constexpr int MED3 = FORM;
     constexpr int FORM_U = (MED3 != 0 && sizeof(T) <= 2) ? MED3 : (CARRY ? 1 : 0);
     constexpr int FORM_B = MED3 != 0 ? MED3 : (CARRY ? 1 : 0);
     auto edge_update = [&](auto S_, auto B_, R x, R uu, auto BND_) LDPC_INLINE {
@@ -1270,7 +1292,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
-                constexpr int CH = 6, NCH = (D + CH - 1) / CH;
+                constexpr int CH = LDPC_LEAN_CH, NCH = (D + CH - 1) / CH;
                 {
                     constexpr int prio_rows[6] = LDPC_PRIO_ROWS_LEAN;
                     constexpr int step = S * NROWS + Rw, nsteps = IPT * NROWS;
@@ -1316,6 +1338,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             if (__ballot(par_any < 0) != 0 && (tid & 63) == 0) flag_at(it) = 1;
             LDPC_SYNC();
             if (flag_at(it) == 0) return true;                                         // :453: every check of the codeword holds
+            tb = t * SZ;
+            asm volatile("" : "+v"(tb));          // pass B recomputes its addresses: none may stay live across the vote
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
                 static_for<0, NROWS>([&](auto R_) LDPC_INLINE { finish_row(S_, R_, sgn_row[decltype(S_)::value][decltype(R_)::value]); });
             });
@@ -1338,7 +1362,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             static_for<0, NROWS>([&](auto R_) LDPC_INLINE {
                 constexpr int Rw = decltype(R_)::value;
                 constexpr int D = row_degree(P, Rw);
-                constexpr int CH = 6, NCH = (D + CH - 1) / CH;
+                constexpr int CH = LDPC_LEAN_CH, NCH = (D + CH - 1) / CH;
                 int par = 0, sgn = 0;
                 R a[D], e[D];                                   // this row's new v, its exclusive minima
                 static_for<0, NCH>([&](auto K_) LDPC_INLINE {
@@ -1579,7 +1603,7 @@ constexpr int min_waves_per_simd()
     return 1;
 }
 
-template <int CODE, class T, int IPT, bool PF, int LEAN>
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM = selfcorr_med3<CODE, T>()>
 __global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
@@ -1597,17 +1621,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // arrivals of the whole workgroup, whichever copy a wave runs).
     if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 0, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
         else
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
         const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
-        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
-        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
-        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
-        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     } else {
-        decode_ms_body<CODE, T, IPT, PF, LEAN, -1>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        decode_ms_body<CODE, T, IPT, PF, LEAN, -1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     }
 }
 

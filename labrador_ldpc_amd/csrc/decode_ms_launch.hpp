@@ -87,7 +87,7 @@ inline uint32_t *claim_counter(hipStream_t stream)
 }
 
 // Resident workgroups per device for one instantiation (occupancy x compute units), cached.
-template <int CODE, class T, int IPT, bool PF, int LEAN>
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM>
 int resident_workgroups()
 {
     using GEO = Geometry<CODE, T, IPT>;
@@ -97,7 +97,7 @@ int resident_workgroups()
     int v = cached[dev].load(std::memory_order_relaxed);
     if (v == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF, LEAN>, GEO::WG, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM>, GEO::WG, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         v = per_cu * cus;
@@ -107,9 +107,9 @@ int resident_workgroups()
 }
 
 // Launch one instantiation (IPT indices per thread; LEAN 1 = register-lean check phase, 2 = in-place messages).
-template <int CODE, class T, int IPT, int LEAN>
-hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                      size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+template <int CODE, class T, int IPT, int LEAN, int FORM>
+hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                           size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
 {
     using GEO = Geometry<CODE, T, IPT>;
     // LLR staging (PF) is implemented but measured SLOWER than plain loads at the start of each
@@ -130,7 +130,7 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // the fixed stride: their decodes take tens of microseconds and a workgroup is expensive to start); the fixed stride on
     // the 16x grid for the smaller ones, where the hardware dispatcher is a queue that costs no atomics (the TC codes' draws
     // would hit the device's ceiling of ~85 M same-address atomics per second: claim_chunk()).
-    const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN>();
+    const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN, FORM>();
     constexpr bool queue_fed = GEO::WG >= 512;
     uint32_t *claim = (static_stride || maxiters == 0 || !queue_fed) ? nullptr : claim_counter(stream);
     // groups per draw: at least ~8 draws per resident workgroup, so that the last chunks are a small part of a short launch
@@ -142,10 +142,28 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     const size_t chunks = (groups + K - 1) / K;
     size_t grid = (resident <= 256 || claim != nullptr) ? resident : resident * 16;
     if (grid > chunks) grid = chunks;
-    constexpr bool clamp_form = std::is_same_v<T, float> && selfcorr_med3<CODE, T>() == 2;
-    hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
+    constexpr bool clamp_form = std::is_same_v<T, float> && FORM == 2;
+    hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
                        llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim, (uint32_t)K);
     return hipGetLastError();
+}
+
+// IPT indices per thread; LEAN 1 = register-lean check phase, 2 = in-place messages.  The f32 kernels with a clamp-free loop
+// exist in two forms of the self-correction: the v_fma clamp (faster: TM2048 40.3 against 38.2, TC512 140.0 against 136.6 M
+// codewords/s) narrows the range vote to |LLR| <= 2^floor(82.5 - log2(7) max_iters) -- 2^12 at the benchmark's 25 iterations,
+// 2^3 at 28; beyond that real LLRs would fall out of the clamp-free loop altogether, so longer decodes run the v_mul_legacy
+// form, whose vote is the clamp-free loop's own.
+template <int CODE, class T, int IPT, int LEAN>
+hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                      size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+{
+    if constexpr (has_nocap_loop<CODE, T, IPT, LEAN>() && selfcorr_med3<CODE, T>() == 2) {
+        if (nocap_limit_for(maxiters, true) >= 8.0f)
+            return launch_cfg_form<CODE, T, IPT, LEAN, 2>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        return launch_cfg_form<CODE, T, IPT, LEAN, 3>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+    } else {
+        return launch_cfg_form<CODE, T, IPT, LEAN, selfcorr_med3<CODE, T>()>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+    }
 }
 
 template <int CODE, class T, int IPT>
@@ -195,7 +213,7 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
     if (batch == 0) return hipSuccess;
     if (batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if constexpr (std::is_same_v<T, float>) {
-        // f32: the v_fmac clamp form (+10 %) narrows the range vote to |LLR| <= 2^floor(82.5 - log2(7) max_iters) -- 2^12 at the
+        // f32: the v_fma clamp form (+10 %) narrows the range vote to |LLR| <= 2^floor(82.5 - log2(7) max_iters) -- 2^12 at the
         // benchmark's 25 iterations, 2^3 at 28; beyond that real LLRs would fall out of the clamp-free loop altogether, so longer
         // decodes run the v_mul_legacy form (+7 %), whose vote is the clamp-free loop's own
         if (nocap_limit_for(maxiters, true) >= 8.0f)

@@ -482,8 +482,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 }
 
 // Self-correction form of the pair kernel.  The clamp forms (Ops<float>::clamp_to_side) replace the compare and the select by
-// one v_med3_f32: TM8192 f32 7.56 -> 8.31 (form 2) / 8.07 (form 3), i8 7.11 -> 7.45 M codewords/s (same-process A/B,
-// profiles/r03_kbench/kb1.txt; identical outputs).  Form 2 is the faster one but narrows the f32 range vote
+// one v_med3_f32: TM8192 f32 7.56 -> 8.32 (form 2) / 8.07 (form 3) / 8.04 (form 5), i8 7.11 -> 7.78 M codewords/s (same-process
+// A/B, profiles/r03_kbench/kb1.txt, kb10_forms.txt; identical outputs).  Form 2 is the faster one but narrows the f32 range vote
 // (nocap_limit_for): the launcher uses it while that limit leaves room for real LLRs and form 3 beyond.
 template <class T>
 constexpr int pair_form_default()

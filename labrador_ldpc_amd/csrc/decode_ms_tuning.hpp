@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_LEAN_CH)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
@@ -29,7 +29,7 @@
 #define LDPC_SELFCORR_CARRY -1
 #endif
 // Self-correction as a clamp, v = med3(nv, 0, nv + old * big) (Ops<float>::clamp_to_side): -1 = per kernel
-// (selfcorr_med3()), 0 = off, 2 = v_fmac form, 3 = v_mul_legacy form.
+// (selfcorr_med3()), 0 = off, 2 = v_fma form, 3 = v_mul_legacy form, 5 = three full-rate operations, no median.
 #ifndef LDPC_SELFCORR_MED3
 #define LDPC_SELFCORR_MED3 -1
 #endif
@@ -89,6 +89,10 @@
 #endif
 #ifndef LDPC_PRIO_ROWS
 #define LDPC_PRIO_ROWS {2, 2, 1, 1, 1, 0}        // priority during the last six (index, check row) steps of the check phase
+#endif
+// edges per request chunk of the register-lean check phase (check_phase_lean)
+#ifndef LDPC_LEAN_CH
+#define LDPC_LEAN_CH 6
 #endif
 #ifndef LDPC_PRIO_ROWS_LEAN
 #define LDPC_PRIO_ROWS_LEAN {3, 3, 3, 2, 1, 0}   // the same for the register-lean check phase

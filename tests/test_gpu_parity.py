@@ -268,7 +268,7 @@ def test_tm2048_clamp_mode_is_chosen_per_codeword():
     _compare(code, llrs, 15)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512], ids=lambda c: c.name)
 def test_clamp_free_path_at_its_magnitude_limit(code):
     """the clamp-free check phase is exact only while no magnitude reaches FLT_MAX, and messages feed
     back, so the admissible |LLR| depends on the iteration count: the host passes 2^floor(126 - log2(7) max_iters)
@@ -277,9 +277,13 @@ def test_clamp_free_path_at_its_magnitude_limit(code):
     clamp-free copy of the loop up to the limit, on the clamped copy just above it and beyond 45 iterations."""
     rng = np.random.default_rng(64)
     signs = np.where(rng.random((24, code.n())) < 0.5, 1.0, -1.0).astype(np.float32)
-    for maxiters in (5, 20, 25, 44, 60, 300):
+    for maxiters in (5, 20, 25, 28, 29, 44, 60, 300):
         e = int(np.floor(126.0 - 2.8074 * maxiters))
-        for mag in (2.0 ** max(e, -120), 2.0 ** min(max(e, -120) + 1, 127), 2.0 ** 64, 1.0):
+        # round 3: the TM8192 pair kernel's clamp form of the self-correction (v = med3(nv, 0, nv + old * 2^126)) narrows the
+        # vote to 2^floor(82.5 - log2(7) max_iters) while that is >= 2^3 (max_iters <= 28) and runs the mul_legacy form beyond
+        e2 = int(np.floor(82.5 - 2.8074 * maxiters))
+        for mag in (2.0 ** max(e, -120), 2.0 ** min(max(e, -120) + 1, 127), 2.0 ** 64, 1.0,
+                    2.0 ** max(e2, -19), 2.0 ** (max(e2, -19) + 1)):
             llrs = signs * np.float32(mag)
             it, ok = _compare(code, llrs, maxiters)
             assert (ok == 0).all() and (it == maxiters).all()
@@ -287,7 +291,7 @@ def test_clamp_free_path_at_its_magnitude_limit(code):
             _compare(code, llrs, maxiters)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512], ids=lambda c: c.name)
 def test_bounded_mode_at_the_small_end_of_its_llr_range(code):
     """The clamp-free copy of the f32 loop also tests the self-correction by a multiply (nv * old < 0), which is
     exact only if no product underflows: its codewords must have every nonzero |LLR| >= 2^-20 (then every nonzero
@@ -360,3 +364,23 @@ def test_launches_on_different_streams_have_their_own_queue():
     torch.cuda.synchronize()
     for st, idx, d, out, it, ok in jobs:
         assert (out.cpu().numpy() == ref[0][idx]).all() and (it.cpu().numpy() == ref[1][idx]).all() and (ok.cpu().numpy() == ref[2][idx]).all()
+
+
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512], ids=lambda c: c.name)
+def test_clamp_form_of_the_self_correction_with_extreme_magnitude_ratios(code):
+    """The clamp form needs big * |old| > |nv| for every nonzero old: frames that mix LLRs at the top of the admitted range
+    with LLRs at its bottom (2^-20) and exact zeros -- so that tiny old messages meet huge new ones, with signs that disagree
+    -- at iteration counts on both sides of the switch between the two forms, all never converging."""
+    rng = np.random.default_rng(0xC1A)
+    n = code.n()
+    for maxiters in (8, 25, 28, 29, 40):
+        top = 2.0 ** max(int(np.floor(82.5 - 2.8074 * maxiters)), 3)
+        frames = []
+        for f in range(16):
+            mags = np.where(rng.random(n) < 0.5, top, 2.0 ** -20) * (1.0 + rng.random(n) * (f % 2))     # exact powers of two / dense mantissas
+            x = np.where(rng.random(n) < 0.5, 1.0, -1.0) * mags
+            x[rng.random(n) < 0.05] = 0.0
+            frames.append(x)
+        llrs = np.asarray(frames, dtype=np.float32)
+        _compare(code, llrs, maxiters)
+        _compare(code, (llrs * np.float32(2.0)).astype(np.float32), maxiters)           # one binade above: the clamped loop

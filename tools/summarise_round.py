@@ -1,9 +1,9 @@
 """Condense gpurun_out/<round> (tools/prof_round.sh) into profiles/<round> and refresh profiles/hbm_traffic.json:
 kernel-trace stats of every decode kernel of the default bench command, per-launch means of every PMC counter per
 configuration, HBM traffic corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950) + WRITE_SIZE.
-    python tools/summarise_round.py r02_final"""
+    python tools/summarise_round.py r03_final"""
 import csv, glob, json, os, shutil, sys
-name = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+name = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 src, dst = f"gpurun_out/{name}", f"profiles/{name}"
 os.makedirs(dst, exist_ok=True)
 def newest(pattern):

@@ -48,6 +48,14 @@ __global__ void __launch_bounds__(1024) spin(float *out, int loops, float seed)
         if (KIND == 27) { BODY("v_pk_max_i16 %0, %5, %1\n v_pk_max_i16 %1, %6, %2\n v_pk_max_i16 %2, %5, %3\n v_pk_max_i16 %3, %6, %0") }
         if (KIND == 28) { BODY("v_pk_add_i16 %0, %5, %1\n v_pk_add_i16 %1, %6, %2\n v_pk_add_i16 %2, %5, %3\n v_pk_add_i16 %3, %6, %0") }
         if (KIND == 29) { BODY("v_and_b32 %0, %5, %1\n v_and_b32 %1, %6, %2\n v_and_b32 %2, %5, %3\n v_and_b32 %3, %6, %0") }
+        // round 3: the pieces of the clamp form of the self-correction (Ops<float>::clamp_to_side)
+        if (KIND == 60) { BODY("v_fmac_f32 %0, %5, %1\n v_fmac_f32 %1, %6, %2\n v_fmac_f32 %2, %5, %3\n v_fmac_f32 %3, %6, %0") }
+        if (KIND == 61) { BODY("v_fma_f32 %0, %5, %1, %6\n v_fma_f32 %1, %6, %2, %5\n v_fma_f32 %2, %5, %3, %6\n v_fma_f32 %3, %6, %0, %5") }
+        if (KIND == 62) { BODY("v_med3_f32 %0, %5, 0, %1\n v_med3_f32 %1, %6, 0, %2\n v_med3_f32 %2, %5, 0, %3\n v_med3_f32 %3, %6, 0, %0") }
+        if (KIND == 63) { BODY("v_mul_legacy_f32_e64 %0, %5, %1\n v_mul_legacy_f32_e64 %1, %6, %2\n v_mul_legacy_f32_e64 %2, %5, %3\n v_mul_legacy_f32_e64 %3, %6, %0") }
+        // the new edge update on four independent edges: sub, mov, fmac, med3 (against KIND 30 / 31: sub, bitop3, cmp, cndmask)
+        if (KIND == 64) { BODY("v_sub_f32 %0, %5, %0\n v_mov_b32 %1, %0\n v_fmac_f32 %1, %7, %2\n v_med3_f32 %2, %0, 0, %1\n"
+                               "v_sub_f32 %3, %6, %3\n v_mov_b32 %1, %3\n v_fmac_f32 %1, %7, %2\n v_med3_f32 %2, %3, 0, %1") }
 
         // ---- mixes of fast (F: v_xor) and slow (S: v_min_f32) independent ops: what does the order cost? ----
         if (KIND == 40) { BODY("v_xor_b32 %0, %5, %0\n v_xor_b32 %2, %5, %2\n v_min_f32 %1, %6, %1\n v_min_f32 %3, %6, %3") }                 // FFSS
@@ -126,6 +134,8 @@ int main()
     run<27>("v_pk_min? v_pk_max_i16");
     run<28>("v_pk_add_i16");
     run<29>("v_and_b32");
+    run<60>("v_fmac_f32 (VOP2)"); run<61>("v_fma_f32 (VOP3)"); run<62>("v_med3_f32 x, 0, y"); run<63>("v_mul_legacy_f32 (VOP3)");
+    run<64>("edge update, clamp form", 8);
 
     run<40>("FFSS", 4); run<41>("FFFFSSSS", 8); run<42>("FFS", 3); run<43>("FFFS", 4); run<44>("FSS", 3);
     run<45>("F dependent chain", 4); run<46>("S dependent chain", 4); run<47>("cmp F cmp F", 4); run<48>("cnd F cnd F", 4);

@@ -2,11 +2,11 @@
 cycle-weighted VALU issue cost it implies (tools/ubench/valu_rate.hip gives the per-class issue cost at four waves
 per SIMD: 2 cycles for plain VOP1/VOP2 ALU operations, 4 for min/max/compare and the VOP3-only forms, ~3 for
 v_bitop3_b32).  Writes profiles/<round>/valu_mix_tm8192_f32.json.
-    python tools/valu_mix.py r02_final"""
+    python tools/valu_mix.py r03_final"""
 import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-name = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+name = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 tmp = tempfile.mkdtemp()
 subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", os.path.join(ROOT, "build/csrc/decode_ms_f32.o"), "/dev/null"])
 subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat", f"--output={tmp}/co", "--unbundle"])
@@ -17,14 +17,14 @@ for l in dis:
     if m:
         cur = m.group(1)
         continue
-    if cur and "decode_ms_pair_kernelILi8Ef" in cur and "//" in l:
+    if cur and "decode_ms_pair_kernelILi8EfLi2E" in cur and "//" in l:      # the form-2 instantiation (the one a 25-iteration launch runs)
         text, tail = l.split("//", 1)
         addr = int(tail.split(":")[0].strip(), 16)
         tgt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", tail)
         body.append((addr, text.strip(), int(tgt.group(1), 16) if tgt else None))
 base = body[0][0]
 # the iteration loops are the backward branches whose span holds exactly two workgroup barriers; one per quarter
-# body and clamp mode.  Take a clamp-FREE one (no v_min_f32 cap operations, multiply-form self-correction test: the mode the
+# body and clamp mode.  Take a clamp-FREE one (no v_min_f32 cap operations, clamp-form self-correction = v_fmac + v_med3: the mode the
 # benchmark's frames run in).
 loops = []
 for i, (addr, text, tgt) in enumerate(body):
@@ -34,15 +34,15 @@ for i, (addr, text, tgt) in enumerate(body):
             span = [t for _, t, _ in body[j:i + 1]]
             if sum(1 for t in span if t.startswith("s_barrier")) == 2:
                 loops.append(span)
-loops.sort(key=lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), -sum(1 for t in sp if t.startswith("v_mul_f32")), len(sp)))
+loops.sort(key=lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), -sum(1 for t in sp if t.startswith("v_fmac_f32")), len(sp)))
 # among the clamp-free copies (as many v_min_f32 / v_mul_f32 as the first) take the one with the LARGEST VALU count: since
 # iteration 0 is peeled the compiler rotates some copies of the loop, and a backward branch can then span a body that
 # lacks the rotated part
-key = lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), sum(1 for t in sp if t.startswith("v_mul_f32")))
+key = lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), sum(1 for t in sp if t.startswith("v_fmac_f32")))
 same = [sp for sp in loops if key(sp) == key(loops[0])]
 quarter = collections.Counter(sum(1 for t in sp if t.startswith("ds_")) for sp in same).most_common(1)[0][0]
 loop = max((sp for sp in same if sum(1 for t in sp if t.startswith("ds_")) == quarter), key=lambda sp: sum(1 for t in sp if t.startswith("v_")))
-FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|fma|pk_|lshl_add|lshl_or|xad)")
+FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|fma_|pk_|lshl_add|lshl_or|xad)")      # (v_fmac_f32_e32 is a plain VOP2: tools/ubench/valu_rate.hip)
 cls = collections.Counter()
 ops = collections.Counter()
 for l in loop:
@@ -58,7 +58,7 @@ for l in loop:
         cls["2-cycle (plain VOP1/VOP2)"] += 1
 n = sum(cls.values())
 avg = (2 * cls["2-cycle (plain VOP1/VOP2)"] + 3 * cls["bitop3 (3 cycles)"] + 4 * cls["4-cycle (min/max/med3/compare/VOP3-only)"]) / n
-out = {"kernel": "decode_ms_pair_kernel<8, float>, one quarter body, clamp-free mode, one iteration (variable + check phase)",
+out = {"kernel": "decode_ms_pair_kernel<8, float, 2>, one quarter body, clamp-free mode, one iteration (variable + check phase)",
        "valu_instructions_per_wave_iteration": n, "classes": dict(cls), "avg_issue_cycles_per_instruction": avg,
        "other": {"ds": sum(1 for l in loop if l.startswith("ds_")), "salu": sum(1 for l in loop if l.startswith("s_"))},
        "top_opcodes": ops.most_common(14),
