@@ -611,17 +611,19 @@ constexpr int selfcorr_med3()
     if (LDPC_SELFCORR_MED3 >= 0) return LDPC_SELFCORR_MED3;
     constexpr bool narrow = sizeof(T) <= 2;
     if (narrow) return (CODE == TM5120 || CODE == TM1280) ? 5 : 2;      // (TM5120, TM1280: the register-lean kernels, launch_one)
-    return (CODE == TM2048 || CODE == TC512) ? 2 : 0;                  // f32: the kernels with a clamp-free loop (has_nocap_loop)
+    return (CODE == TM2048 || CODE == TC512 || CODE == TM1536) ? 2 : 0;    // f32: the kernels with a clamp-free loop (has_nocap_loop)
 }
 
 // f32 kernels that carry a second, clamp-free copy of their iteration loop (NOCAP_POSSIBLE in the kernel body)
 template <int CODE, class T, int IPT, int LEAN>
 constexpr bool has_nocap_loop()
 {
+    // (TM1536: 65.7 -> 69.2 M codewords/s with the loop and the clamp form; TM6144 loses 2 % -- its local-edge updates
+    // in the variable phase keep the multiply / clamp forms out; TM1280 spills: profiles/r03_kbench/kb14.txt)
 #ifdef LDPC_NOCAP_ALSO
-    constexpr bool code = CODE == TM2048 || CODE == TC512 || CODE == LDPC_NOCAP_ALSO;     // (kbench experiment)
+    constexpr bool code = CODE == TM2048 || CODE == TC512 || CODE == TM1536 || CODE == LDPC_NOCAP_ALSO;     // (kbench experiment)
 #else
-    constexpr bool code = CODE == TM2048 || CODE == TC512;
+    constexpr bool code = CODE == TM2048 || CODE == TC512 || CODE == TM1536;
 #endif
     return LDPC_NOCAP != 0 && std::is_same_v<T, float> && code && Geometry_G<CODE, IPT>() == 1 && LEAN == 0 && IPT == 1;
 }

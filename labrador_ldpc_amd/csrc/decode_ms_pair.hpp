@@ -30,6 +30,8 @@ namespace ldpc {
 // per wave: cycles in [variable phase, wait at barrier 2, check phase, wait at barrier 1], summed over iterations
 // [4] = ticks from the first begin_codeword to the end of the last epilogue, [5] = the same in s_memrealtime (100 MHz) ticks
 __device__ unsigned long long g_stamps[256 * 16 * 6];
+// per wave: [0] the longest and [1] the shortest check phase seen, [2] the longest wait at the barrier behind it, [3] the shortest
+__device__ unsigned long long g_stamp_ext[256 * 16 * 4];
 // absolute s_memrealtime at workgroup entry / at the start of the codeword loop / at exit, last launch only
 __device__ unsigned long long g_wg_times[256 * 3];
 #endif
@@ -80,8 +82,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     constexpr int Q = M / 4, IPT = 2;
     constexpr int BLK_BYTES = M * 4, FLAG_OFF = (NX + NXC) * BLK_BYTES;
     // odd rotations read their two marginals as halves of two aligned 64-bit pairs (see check_phase): +12 % for
-    // i8 (8.0 -> 9.0 M codewords/s), but the wider destinations cost f32 nine spilled VGPRs (6.7 -> 6.5)
-    constexpr bool ODD_B64 = LDPC_PAIR_ODD_B64 >= 0 ? LDPC_PAIR_ODD_B64 != 0 : !std::is_same_v<T, float>;
+    // i8 (8.0 -> 9.0 M codewords/s).  For f32 the wider destinations cost nine spilled VGPRs in round 1 (6.7 -> 6.5) and
+    // nothing either way in round 2 (7.00 / 7.00); with round 3's shorter check phase (the clamp form of the self-correction
+    // frees the VCC round trips and two registers) the 20 % of LDS cycles lost to the 2-way conflicts of the 32-bit reads
+    // show: 8.32-8.33 -> 8.43-8.45 M codewords/s, 2 spilled registers instead of 3 (profiles/r03_kbench/kb13.txt).
+    constexpr bool ODD_B64 = LDPC_PAIR_ODD_B64 >= 0 ? LDPC_PAIR_ODD_B64 != 0 : true;
     constexpr int LOCAL_IN_VAR = LDPC_PAIR_LOCAL_IN_VAR >= 0 ? LDPC_PAIR_LOCAL_IN_VAR : (std::is_same_v<T, float> ? 10 : 8);
     constexpr bool PRIO_WAVES = true;            // LDPC_SETPRIO (decode_ms_kernel.hpp)
     (void)PRIO_WAVES;
@@ -385,6 +390,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         uint32_t iters = maxiters;
 #ifdef LDPC_DIAG_STAMPS
         unsigned long long acc_var = 0, acc_w2 = 0, acc_chk = 0, acc_w1 = 0, t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long chk_max = 0, chk_min = ~0ull, w1_max = 0, w1_min = ~0ull;
 #endif
         // the iterations, as one loop per clamp mode (two check phases inside ONE loop cost 330 spilled VGPRs)
         auto iterate = [&](auto CAP_) LDPC_INLINE {
@@ -401,7 +407,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 if (it > 0) LDPC_SYNC();          // (the barrier before iteration 0 is taken below, before the clamp mode is read)
 #ifdef LDPC_DIAG_STAMPS
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                if (it > 0) acc_w1 += t0 - t3;
+                if (it > 0) { acc_w1 += t0 - t3; if (t0 - t3 > w1_max) w1_max = t0 - t3; if (t0 - t3 < w1_min) w1_min = t0 - t3; }
 #endif
                 if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
                 else if (it == maxiters) { done = true; }
@@ -422,6 +428,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 t3 = __builtin_amdgcn_s_memtime();
                 acc_var += t1 - t0; acc_w2 += t2 - t1; acc_chk += t3 - t2;
+                if (t3 - t2 > chk_max) chk_max = t3 - t2;
+                if (t3 - t2 < chk_min) chk_min = t3 - t2;
 #endif
             }
         };
@@ -436,6 +444,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         if ((t & 63) == 0 && blockIdx.x < 256) {
             unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 6;
             d[0] += acc_var; d[1] += acc_w2; d[2] += acc_chk; d[3] += acc_w1;
+            unsigned long long *x = g_stamp_ext + ((size_t)blockIdx.x * 16 + t / 64) * 4;
+            if (chk_max > x[0]) x[0] = chk_max;
+            if (x[1] == 0 || chk_min < x[1]) x[1] = chk_min;
+            if (w1_max > x[2]) x[2] = w1_max;
+            if (x[3] == 0 || w1_min < x[3]) x[3] = w1_min;
         }
 #endif
         // the next codeword's LLR loads, issued before this one's epilogue (fixed cost per codeword 2.55 -> 2.12 us)

@@ -121,8 +121,8 @@
 #ifndef LDPC_PAIR_NOCAP
 #define LDPC_PAIR_NOCAP 1
 #endif
-// Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = per type (on for
-// i8/i16: 8.0 -> 9.0; off for f32: 7.05 -> 6.90), 0 / 1 = force.
+// Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = the default (on: i8/i16 8.0 -> 9.0 in
+// round 1; f32 7.05 -> 6.90 then, 8.33 -> 8.44 with round 3's check phase), 0 / 1 = force.
 #ifndef LDPC_PAIR_ODD_B64
 #define LDPC_PAIR_ODD_B64 -1
 #endif

@@ -98,3 +98,48 @@ def test_full_batch_properties(code, dtype, frames, ebn0):
     tx = d_pool[(succ_idx % d_pool.shape[0])]
     same = (out[succ_idx][:, : code.n() // 8] == tx).all(dim=1).float().mean()
     assert float(same) > 0.999
+
+
+def test_config4_whole_batch_on_one_gpu():
+    """BASELINE config 4 as the metric quotes it: ALL 4 194 304 TM8192 f32 frames (137 GB of LLRs) in one device-resident batch
+    -- what `bench.py` times at N = 1 (round 2's review, item 1).  Queue-fed and fixed-stride distribution give identical
+    results; the first and the last 524 288-frame slice (what GPUs 0 and 7 of an 8-GPU run decode) decoded alone equal their
+    part of the whole; oracle samples from the start, the middle and the very end of the buffer; idempotence on a subset."""
+    code, frames, maxiters = LDPCCode.TM8192, 4194304, 25
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 160 * 2 ** 30:
+        pytest.skip(f"needs ~150 GB of free HBM, {free / 2 ** 30:.0f} GB available")
+    sigma = float(np.sqrt(1.0 / (2.0 * 0.5 * 10.0 ** 0.2)))
+    d_pool = torch.from_numpy(_pool(code, 64, 0x1DBC + int(code))).to(dev)
+    llrs = code.awgn_frames(d_pool, frames, sigma, seed=0x1DBC + int(code), dtype="f32")
+    out, iters, ok = code.decode_ms_batch(llrs, maxiters)
+    torch.cuda.synchronize()
+    okb = ok.bool()
+    assert bool((iters[okb] < maxiters).all()) and bool((iters[~okb] == maxiters).all())
+    assert 0.99 < float(okb.float().mean()) < 1.0                       # 2 dB: a frame in ~1 600 fails
+
+    out2 = torch.empty_like(out)
+    it2, ok2 = torch.empty_like(iters), torch.empty_like(ok)
+    code.decode_ms_batch(llrs, maxiters, output=out2, iters=it2, success=ok2, variant=256)          # fixed stride
+    assert torch.equal(out, out2) and torch.equal(iters, it2) and torch.equal(ok, ok2)
+    del out2
+
+    S = 524288
+    for lo in (0, frames - S):
+        o_s, i_s, k_s = code.decode_ms_batch(llrs[lo:lo + S], maxiters)
+        assert torch.equal(o_s, out[lo:lo + S]) and torch.equal(i_s, iters[lo:lo + S]) and torch.equal(k_s, ok[lo:lo + S])
+        del o_s
+
+    for lo in (0, frames // 2 - 128, frames - 256):
+        h = llrs[lo:lo + 256].cpu().numpy()
+        o_c, i_c, k_c, _ = oracle.decode_ms_batch(code, h, maxiters)
+        assert (out[lo:lo + 256].cpu().numpy() == o_c).all()
+        assert (iters[lo:lo + 256].cpu().numpy().astype(np.int64) == i_c.astype(np.int64)).all()
+        assert (ok[lo:lo + 256].cpu().numpy() == k_c).all()
+    del llrs
+
+    sub = torch.nonzero(okb[-65536:]).flatten() + (frames - 65536)
+    clean = _hard_llrs(code, out[sub], "f32")
+    o3, i3, k3 = code.decode_ms_batch(clean, maxiters)
+    assert bool((k3 == 1).all()) and bool((i3 <= 1).all()) and torch.equal(o3, out[sub])

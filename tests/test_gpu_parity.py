@@ -268,7 +268,7 @@ def test_tm2048_clamp_mode_is_chosen_per_codeword():
     _compare(code, llrs, 15)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512, LDPCCode.TM1536], ids=lambda c: c.name)
 def test_clamp_free_path_at_its_magnitude_limit(code):
     """the clamp-free check phase is exact only while no magnitude reaches FLT_MAX, and messages feed
     back, so the admissible |LLR| depends on the iteration count: the host passes 2^floor(126 - log2(7) max_iters)
@@ -291,7 +291,7 @@ def test_clamp_free_path_at_its_magnitude_limit(code):
             _compare(code, llrs, maxiters)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512, LDPCCode.TM1536], ids=lambda c: c.name)
 def test_bounded_mode_at_the_small_end_of_its_llr_range(code):
     """The clamp-free copy of the f32 loop also tests the self-correction by a multiply (nv * old < 0), which is
     exact only if no product underflows: its codewords must have every nonzero |LLR| >= 2^-20 (then every nonzero
@@ -366,7 +366,7 @@ def test_launches_on_different_streams_have_their_own_queue():
         assert (out.cpu().numpy() == ref[0][idx]).all() and (it.cpu().numpy() == ref[1][idx]).all() and (ok.cpu().numpy() == ref[2][idx]).all()
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TM8192, LDPCCode.TM2048, LDPCCode.TC512, LDPCCode.TM1536], ids=lambda c: c.name)
 def test_clamp_form_of_the_self_correction_with_extreme_magnitude_ratios(code):
     """The clamp form needs big * |old| > |nv| for every nonzero old: frames that mix LLRs at the top of the admitted range
     with LLRs at its bottom (2^-20) and exact zeros -- so that tiny old messages meet huge new ones, with signs that disagree
@@ -384,3 +384,14 @@ def test_clamp_form_of_the_self_correction_with_extreme_magnitude_ratios(code):
         llrs = np.asarray(frames, dtype=np.float32)
         _compare(code, llrs, maxiters)
         _compare(code, (llrs * np.float32(2.0)).astype(np.float32), maxiters)           # one binade above: the clamped loop
+
+
+def test_baseline_config1_through_the_single_frame_entry():
+    """BASELINE.json configs[0] verbatim (TC128, one codeword, 50 iterations, AWGN 3 dB) through the reference-shaped
+    labrador_ldpc_decode_ms_f32 (capi/src/lib.rs:113-119): the frame and its frozen result of tests/test_oracle_kats.py."""
+    code = LDPCCode.TC128
+    rng = np.random.default_rng(0x1DBC + int(code))
+    llrs, _ = oracle.awgn_llrs(code, rng, 1, 3.0, np.float32)
+    out = np.zeros(code.output_len(), dtype=np.uint8)
+    ok, iters = code.decode_ms(llrs[0], out, maxiters=50)
+    assert ok and iters == 3 and out.tobytes().hex() == "1883fafcd83eb9577b082a4694f949c4"

@@ -133,3 +133,24 @@ def test_decode_bf_doctest_round_trip():
     rx[0] ^= 1 << 7
     ok, iters, out = oracle.decode_bf(code, rx, 20)
     assert ok and (out[: oracle.k(code) // 8] == cw[: oracle.k(code) // 8]).all()
+
+
+def test_baseline_config1_tc128_one_codeword_50_iterations_3db():
+    """BASELINE.json configs[0], verbatim: TC128 (k=128 r=1/2) decode_ms on the CPU path, ONE codeword, 50 iterations, AWGN at
+    Eb/N0 = 3 dB -- the reference's own CPU-runnable shape (capi/src/lib.rs:83-95: one frame, caller-owned buffers).  The frame
+    is the one bench.py's config-1 leg decodes (seed 0x1DBC + code); the C oracle and the numpy restatement agree on it, and the
+    result is frozen here (the GPU's single-frame entry must reproduce it: tests/test_gpu_parity.py)."""
+    import hashlib
+    import sys
+    sys.path.insert(0, oracle.ORACLE_DIR)
+    import ms_numpy
+    code = 0
+    rng = np.random.default_rng(0x1DBC + code)
+    llrs, cws = oracle.awgn_llrs(code, rng, 1, 3.0, np.float32)
+    assert hashlib.sha256(llrs.tobytes()).hexdigest()[:16] == "6e3581acdada44cc"        # the frame itself is pinned
+    ok, iters, out = oracle.decode_ms(code, llrs[0], 50)
+    chk, var = oracle.edges(code)
+    o2, i2, k2 = ms_numpy.decode_ms(ms_numpy.Structure(chk, var, oracle.n(code) + oracle.p(code)), llrs, oracle.n(code), 50)
+    assert ok and iters == 3 and out.tobytes().hex() == "1883fafcd83eb9577b082a4694f949c4"
+    assert (o2[0] == out).all() and int(i2[0]) == 3 and int(k2[0]) == 1
+    assert (out[: oracle.n(code) // 8] == cws[0]).all()                                  # and it is the transmitted codeword

@@ -142,6 +142,25 @@ int main()
             printf("  last launch, s_memrealtime relative to the first workgroup's entry: last entry %.3f ms, last loop start %.3f ms, first exit %.3f ms, last exit %.3f ms\n",
                    (e1 - e0) / 1e5, (l0 - e0) / 1e5, (x0 - e0) / 1e5, (x1 - e0) / 1e5);
         }
+        {   // per wave of the workgroup (wave w runs on SIMD w % 4; waves 4q .. 4q+3 own quarter q)
+            double pw[16][4] = {};
+            for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) for (int k = 0; k < 4; ++k) pw[w][k] += st[(b * 16 + w) * 6 + k];
+            for (int w = 0; w < 16; ++w)
+                printf("  wave %2d (SIMD %d): variable %4.0f | wait2 %4.0f | check %4.0f | wait1 %4.0f\n", w, w % 4, pw[w][0] / 256 / (iters_total / 256),
+                       pw[w][1] / 256 / (iters_total / 256), pw[w][2] / 256 / (iters_total / 256), pw[w][3] / 256 / (iters_total / 256));
+        }
+        {
+            std::vector<unsigned long long> ex(256 * 16 * 4);
+            CK(hipMemcpyFromSymbol(ex.data(), HIP_SYMBOL(ldpc::g_stamp_ext), ex.size() * 8));
+            for (int w = 0; w < 16; w += 4) {
+                unsigned long long cmx = 0, cmn = ~0ull, wmx = 0, wmn = ~0ull;
+                for (int b = 0; b < 256; ++b) {
+                    const unsigned long long *x = &ex[(b * 16 + w) * 4];
+                    cmx = x[0] > cmx ? x[0] : cmx; cmn = (x[1] && x[1] < cmn) ? x[1] : cmn; wmx = x[2] > wmx ? x[2] : wmx; wmn = (x[3] && x[3] < wmn) ? x[3] : wmn;
+                }
+                printf("  wave %2d over all workgroups and iterations: check phase %llu .. %llu ticks, wait behind it %llu .. %llu\n", w, cmn, cmx, wmn, wmx);
+            }
+        }
         for (int q = 0; q < 4; ++q)
             printf("  quarter %d waves: variable %.0f | wait2 %.0f | check %.0f | wait1 %.0f\n", q, perq[q][0] / 1024 / (iters_total / 256), perq[q][1] / 1024 / (iters_total / 256),
                    perq[q][2] / 1024 / (iters_total / 256), perq[q][3] / 1024 / (iters_total / 256));

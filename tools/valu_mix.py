@@ -42,7 +42,7 @@ key = lambda sp: (sum(1 for t in sp if t.startswith("v_min_f32")), sum(1 for t i
 same = [sp for sp in loops if key(sp) == key(loops[0])]
 quarter = collections.Counter(sum(1 for t in sp if t.startswith("ds_")) for sp in same).most_common(1)[0][0]
 loop = max((sp for sp in same if sum(1 for t in sp if t.startswith("ds_")) == quarter), key=lambda sp: sum(1 for t in sp if t.startswith("v_")))
-FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|fma_|pk_|lshl_add|lshl_or|xad)")      # (v_fmac_f32_e32 is a plain VOP2: tools/ubench/valu_rate.hip)
+FOUR = re.compile(r"^v_(min3|max3|med3|min_|max_|cmp|cmpx|cndmask_b32_e64|bfi|and_or|or3|add3|perm|alignbit|mad|pk_|lshl_add|lshl_or|xad)")      # (v_fma_f32 / v_fmac_f32 / v_mul_legacy_f32 issue at the full rate on gfx950: profiles/r03_final/valu_rate.txt)
 cls = collections.Counter()
 ops = collections.Counter()
 for l in loop:
