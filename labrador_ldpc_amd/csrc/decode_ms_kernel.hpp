@@ -1591,8 +1591,12 @@ constexpr int min_waves_per_simd()
 #ifdef LDPC_MINW_CODE                                  // (tools/kbench.hip experiments)
     if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
 #endif
-    if (sizeof(T) > 4) return 1;
+    // f64 on TC128 / TC256: 252-253 registers in round 2, 264-268 with round 3's additions -- one wave per SIMD instead of
+    // two (694 -> 487, 383 -> 252 M codewords/s); held at 256
+    if (sizeof(T) > 4) return (CODE <= TC256 && IPT == 1 && LEAN == 0) ? 2 : 1;
     if (LEAN == 1) return 4;
+    // i32 on TC512: 127 -> 129 registers with the queue plumbing (which one-wave workgroups never use): held at 128
+    if (CODE == TC512 && IPT == 1 && std::is_same_v<T, int32_t>) return 4;
     if (CODE == TM2048 && IPT == 1) return LDPC_TM2048_WAVES;
     if (CODE == TM1280 && IPT == 1) return 3;         // 183 -> 168 VGPRs: f32 28.4 -> 38.6, i8 27.0 -> 34.4 M codewords/s
     // TC codes (one-wave workgroups, occupancy set by registers alone): at 139-149 VGPRs three waves per SIMD.  Capping

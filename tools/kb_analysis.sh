@@ -10,7 +10,7 @@ kb() {   # label, flags...
 }
 echo "== shipped kernel, early termination (2 dB, 65536 frames, persistent grid of 256 workgroups) =="
 kb "shipped" -DKFRAMES=65536
-KB_TAIL=9 kb "phase stamps (s_memtime; perturbs the timing)" -DKFRAMES=65536 -DLDPC_DIAG_STAMPS
+KB_TAIL=31 kb "phase stamps (s_memtime; perturbs the timing)" -DKFRAMES=65536 -DLDPC_DIAG_STAMPS
 kb "odd rotations as aligned 64-bit reads (LDPC_PAIR_ODD_B64=1)" -DKFRAMES=65536 -DLDPC_PAIR_ODD_B64=1
 echo "== leave-one-out, 25 iterations for every frame (results wrong by construction) =="
 for v in "" NOSELFCORR NOMIN NOSIGN NOPAR NOBARRIER; do
