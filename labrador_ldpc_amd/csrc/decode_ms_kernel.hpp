@@ -183,6 +183,7 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     LDPC_DEV static R canon_late(R x) { return __builtin_fminf(x + 0.0f, __builtin_inff()); }
 #endif
     LDPC_DEV static R keep_raw(float x) { return x; }
+    LDPC_DEV static R load_nonan(float x) { return x + 0.0f; }                   // for values a vote has shown to hold no NaN
     LDPC_DEV static float store(R x) { return x; }
     LDPC_DEV static R from_lds(float x) { return x; }                           // already canonical
     LDPC_DEV static int bits(R x) { return __float_as_int(x); }
@@ -349,6 +350,7 @@ template <> struct Ops<double> {
     LDPC_DEV static R load(double x) { return __builtin_fmin(x + 0.0, __builtin_inf()); }      // -0.0 -> +0.0, NaN -> +inf: see Ops<float>::load
     LDPC_DEV static R canon_late(R x) { return __builtin_fmin(x + 0.0, __builtin_inf()); }
     LDPC_DEV static R keep_raw(double x) { return x; }
+    LDPC_DEV static R load_nonan(double x) { return x + 0.0; }
     LDPC_DEV static double store(R x) { return x; }
     LDPC_DEV static R from_lds(double x) { return x; }
     LDPC_DEV static int bits(R x) { return __double2hiint(x); }
@@ -388,6 +390,7 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
     LDPC_DEV static R load(I x) { return (float)(int)x; }                       // never -0.0
     LDPC_DEV static R canon_late(R x) { return x; }
     LDPC_DEV static R keep_raw(I x) { return (float)(int)x; }
+    LDPC_DEV static R load_nonan(I x) { return (float)(int)x; }
     LDPC_DEV static R clamp(R x) { return __builtin_amdgcn_fmed3f(x, (float)LO, (float)HI); }
     LDPC_DEV static R add(R a, R b) { return clamp(a + b); }                    // saturating_add
     LDPC_DEV static R sub(R a, R b) { return clamp(a - b); }                    // saturating_sub
@@ -460,6 +463,7 @@ template <> struct Ops<int32_t> {
     LDPC_DEV static R load(int32_t x) { return x; }
     LDPC_DEV static R canon_late(R x) { return x; }
     LDPC_DEV static R keep_raw(int32_t x) { return x; }
+    LDPC_DEV static R load_nonan(int32_t x) { return x; }
     LDPC_DEV static float store(R x) { return __int_as_float(x); }
     LDPC_DEV static R from_lds(float x) { return __float_as_int(x); }
     LDPC_DEV static int bits(R x) { return x; }
@@ -919,6 +923,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // float LLRs: canonicalise the finished marginals instead of the LLRs (Ops<float>::canon_late) -- the register-lean kernels,
     // which re-read their LLRs in every variable phase, and TM1280 f32
     constexpr bool LATE_CANON = std::is_floating_point_v<T> && (LEAN != 0 || (CODE == TM1280 && IPT == 1));
+    // (Tried for the register-lean f32 kernel, which cannot afford even that -- 45 more spilled registers, TM5120 f32 17.1 ->
+    // 14.4 M codewords/s: look for a NaN among a codeword's LLRs once, before the first pass, and run a second copy of the loop
+    // that canonicalises only for codewords that have one.  The second copy alone costs more: 120 spilled registers, 13.3 M
+    // codewords/s (LDPC_NANVOTE, kbench only; profiles/r03_kbench/kb16_nanvote.txt).  What is left is DESIGN.md 7 (c).)
+#ifdef LDPC_NANVOTE
+    constexpr bool NANVOTE = LDPC_NANVOTE != 0 && LATE_CANON && LEAN == 1 && std::is_same_v<T, float> && G == 1;
+#else
+    constexpr bool NANVOTE = false;
+#endif
     constexpr bool ZERO_FREE = PEEL_FIRST;
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
         if constexpr (PF) {
@@ -967,6 +980,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
             if constexpr (GEO::WG == 64) cap_wave = __ballot(big) != 0;          // one wave = one codeword: no LDS word needed
             else if (__ballot(big) != 0 && (tid & 63) == 0) cap_flag() = 1;
+        } else if constexpr (NANVOTE) {
+            bool nn = false;
+            static_for<0, IPT>([&](auto S_) LDPC_INLINE {
+                static_for<0, NTX>([&](auto C_) LDPC_INLINE {
+                    const T x = (llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(decltype(C_)::value * M + decltype(S_)::value * NT) + (unsigned)t];
+                    nn |= x != x;
+                });
+            });
+            if (__ballot(nn) != 0 && (tid & 63) == 0) cap_flag() = 1;           // (the clamp-vote word serves as the NaN vote here)
         } else {
             if (t == 2) *reinterpret_cast<int *>(gbase + FLAG_OFF + 8) = 0;  // (the clamp-vote word, unused here)
         }
@@ -1018,8 +1040,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // One iteration of message passing for this thread's indices: the two phases below.
     // FIRST_: iteration 0 of a codeword, peeled by kernels with PEEL_FIRST -- every u is zero, so the marginals are the
     // LLRs and nothing is read from LDS
-    auto variable_phase = [&](auto FIRST_) LDPC_INLINE {
+    // CANON_ (NANVOTE kernels): this codeword has a NaN LLR -- canonicalise the finished marginals; 0 = the common copy
+    auto variable_phase = [&](auto FIRST_, auto CANON_) LDPC_INLINE {
         constexpr bool FIRST = decltype(FIRST_)::value != 0;
+        constexpr bool CANON = LATE_CANON && (!NANVOTE || decltype(CANON_)::value != 0);
         // marginals (decoder.rs:382-383, :408)
         int tv = t;
         if constexpr (INPLACE) asm volatile("" : "+v"(tv));     // keep the (large-offset) LDS addresses out of loop-carried VGPRs
@@ -1035,7 +1059,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     if constexpr (PACKED_LLR) acc = O::load((T)(llr_pk[S][C / PER_REG] >> (PK_BITS * (C % PER_REG))));
                     else if constexpr (LEAN) {
                         const T x = (llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(C * M) + (unsigned)i];
-                        acc = LATE_CANON ? O::keep_raw(x) : O::load(x);
+                        acc = CANON ? O::keep_raw(x) : (NANVOTE ? O::load_nonan(x) : O::load(x));
                     }
                     else acc = llr[S][C];
                 }
@@ -1050,7 +1074,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                             acc = O::add(acc, ue[B]);                                  // :408
                         }
                     });
-                    if constexpr (LATE_CANON && C < NTX) acc = O::canon_late(acc);   // (see Ops<float>::canon_late)
+                    if constexpr (CANON && C < NTX) acc = O::canon_late(acc);        // (see Ops<float>::canon_late)
                     if constexpr (col_slot(P, C) < 0) va[S][C] = acc;               // exchanged columns: only the sign word is kept (hi array)
                     static_for<0, NB>([&](auto B_) LDPC_INLINE {                       // nv = va - u (:421), in place
                         constexpr int B = decltype(B_)::value;
@@ -1076,7 +1100,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                         else acc = O::add(acc, u[S][B]);
                     }
                 });
-                if constexpr (LATE_CANON && C < NTX) acc = O::canon_late(acc);     // (see Ops<float>::canon_late)
+                if constexpr (CANON && C < NTX) acc = O::canon_late(acc);          // (see Ops<float>::canon_late)
                 va[S][C] = acc;
                 constexpr int cs = col_slot(P, C);
                 if constexpr (cs >= 0) {
@@ -1450,7 +1474,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
-    if constexpr (NOCAP_POSSIBLE && GEO::WG != 64) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
+    if constexpr ((NOCAP_POSSIBLE && GEO::WG != 64) || NANVOTE) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
     if (blockIdx.x * CLAIM_K < n_groups) fetch_llrs(G == 1 ? blockIdx.x * CLAIM_K : blockIdx.x * CLAIM_K * G + grp);
     uint32_t chunk = blockIdx.x, g = chunk * CLAIM_K, g_end = g + CLAIM_K;       // [g, g_end): the rest of the current chunk
     for (uint32_t first = 1; g < n_groups; first = 0) {
@@ -1479,7 +1503,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if (maxiters == 0) done = true;
         if constexpr (G == 1) { if (done) return; }
         else { if (__all(done)) return; }
-        if (G == 1 || !done) variable_phase(IC<1>{});
+        if (G == 1 || !done) variable_phase(IC<1>{}, CAP_);
         LDPC_SYNC();
         if (G == 1 || !done) {
             if constexpr (LEAN == 1) { if (check_phase_lean(0u, IC<1>{})) { done = true; ok = true; iters = 0; } }
@@ -1501,7 +1525,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         if constexpr (G == 1) { if (done) break; }
         else { if (__all(done)) break; }
 
-        if (G == 1 || !done) variable_phase(IC<0>{});
+        if (G == 1 || !done) variable_phase(IC<0>{}, CAP_);
         LDPC_SYNC();
         if constexpr (!WAVE_VERDICT) { if (it > 0 && t == 0) flag_at(it - 1) = 0; }
         if (G == 1 || !done) {
@@ -1513,7 +1537,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     }
     };
     LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
-    if constexpr (NOCAP_POSSIBLE) {
+    if constexpr (NOCAP_POSSIBLE || NANVOTE) {
         if (GEO::WG == 64 ? cap_wave : __builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
         else iterate(IC<0>{});
     } else {
@@ -1553,7 +1577,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         });
     }
     if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
-    if constexpr (NOCAP_POSSIBLE && GEO::WG != 64) { if (t == 0) cap_flag() = 0; }
+    if constexpr ((NOCAP_POSSIBLE && GEO::WG != 64) || NANVOTE) { if (t == 0) cap_flag() = 0; }
     if constexpr (!CLAIM_AHEAD) {
         if (dyn && fresh && tid == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         collect_claim();
