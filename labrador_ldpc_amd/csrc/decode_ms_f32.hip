@@ -4,6 +4,16 @@
 
 namespace ldpc {
 
+// instantiated in decode_ms_f32_part.hip (three more objects: this one alone took 3 min 40 s of a 4 min build)
+#define LDPC_F32_SIG (const float *, uint8_t *, uint32_t *, uint8_t *, size_t, uint32_t, hipStream_t, unsigned)
+extern template hipError_t launch_pair<TM8192, float> LDPC_F32_SIG;
+extern template hipError_t launch_pair<TM2048, float> LDPC_F32_SIG;
+extern template hipError_t launch_one<TM8192, float, 2> LDPC_F32_SIG;
+extern template hipError_t launch_one<TM8192, float, 4> LDPC_F32_SIG;
+extern template hipError_t launch_one<TM5120, float, 1> LDPC_F32_SIG;
+extern template hipError_t launch_one<TM6144, float, 1> LDPC_F32_SIG;
+extern template hipError_t launch_one<TM6144, float, 2> LDPC_F32_SIG;
+
 template <>
 hipError_t launch_decode_ms<float>(int code, int variant, const float *llrs, uint8_t *output,
                                    uint32_t *iters, uint8_t *success, size_t batch,
@@ -14,8 +24,8 @@ hipError_t launch_decode_ms<float>(int code, int variant, const float *llrs, uin
     // (t, t + M/2) kernel with that many indices per thread, 32 = the pair kernel explicitly (TM8192, TM2048; for TM6144 the compiler's control-flow structurizer turns
     // its four quarter bodies into EXEC-masked loops -- 100x slower, so it is not built)
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
-        if (code == TM8192) return launch_pair<TM8192, float>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
-        if (code == TM2048) return launch_pair<TM2048, float>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        if (code == TM8192) return launch_pair<TM8192, float>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+        if (code == TM2048) return launch_pair<TM2048, float>(llrs, output, iters, success, batch, maxiters, stream, lflags);
         return hipErrorInvalidConfiguration;
     }
     switch (code) {

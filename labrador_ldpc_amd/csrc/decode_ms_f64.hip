@@ -182,7 +182,7 @@ hipError_t launch_decode_ms<double>(int code, int variant, const double *llrs, u
 {
     if (batch == 0) return hipSuccess;
     if (!valid_code(code)) return hipErrorInvalidValue;
-    if (variant >= 0) variant &= ~VARIANT_STATIC;          // (the f64 kernels always draw from the launch's queue)
+    if (variant >= 0) variant &= ~VARIANT_FLAGS;           // (the f64 kernels always draw from the launch's queue)
     if (variant == 0) {
         static constexpr int tuned[NUM_CODES] = {1, 1, 1, 1, 1, 17, 17, 33, 34};
         variant = tuned[code];

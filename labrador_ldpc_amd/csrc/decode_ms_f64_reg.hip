@@ -29,7 +29,7 @@ int code, int ipt, int lean, const double *llrs, uint8_t *output, uint32_t *iter
 {
 #define F64_CFG(CODE, IPT, LEAN)                                                                                     \
     if (code == CODE && ipt == IPT && lean == LEAN)                                                                  \
-        return launch_cfg<CODE, double, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, false);
+        return launch_cfg<CODE, double, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, 0u);
 #if F64_PART == 0
     F64_CFG(TC128, 1, 0)  F64_CFG(TC128, 1, 1)
     F64_CFG(TC256, 1, 0)  F64_CFG(TC256, 1, 1)

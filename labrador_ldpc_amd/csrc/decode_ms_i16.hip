@@ -12,7 +12,7 @@ hipError_t launch_decode_ms<int16_t>(int code, int variant, const int16_t *llrs,
     LDPC_SPLIT_VARIANT();
     // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
-        if (code == TM8192) return launch_pair<TM8192, int16_t>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        if (code == TM8192) return launch_pair<TM8192, int16_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);
         return hipErrorInvalidConfiguration;
     }
     switch (code) {

@@ -12,7 +12,7 @@ hipError_t launch_decode_ms<int32_t>(int code, int variant, const int32_t *llrs,
 {
     LDPC_SPLIT_VARIANT();
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
-        if (code == TM8192) return launch_pair<TM8192, int32_t>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        if (code == TM8192) return launch_pair<TM8192, int32_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);
         return hipErrorInvalidConfiguration;
     }
     switch (code) {

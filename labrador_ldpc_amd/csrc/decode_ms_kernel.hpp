@@ -659,6 +659,10 @@ constexpr bool peel_first_default()
     return false;
 }
 
+// What the first of two NaN passes leaves in iters_out for a codeword with a NaN LLR (decode_ms_body, NANPASS): no iteration
+// count -- the launcher runs two passes only for max_iters below it
+constexpr uint32_t NAN_MARK = 0xFFFFFFFFu;
+
 // Most codeword groups a workgroup takes per draw from the launch's queue (decode_ms_body, "dynamic distribution").  The
 // draws of a launch are atomics on ONE address, and the device sustains 85-90 million of those per second whatever else it
 // does (measured: TC512 at 5 dB through the queue with two groups per draw stops at 172 M codewords/s against 600 with the
@@ -721,7 +725,11 @@ LDPC_DEV int pi_dev(int i, int j)
 // JW >= 0: the body is specialised for waves whose indices start in quarter JW (the kernel
 // branches once, wave-uniformly, into the matching copy) so that every rotation constant of the
 // pi_k blocks is a literal; JW < 0: generic body, constants in SGPRs.
-template <int CODE, class T, int IPT, bool PF, int LEAN, int JW, int FORM>
+// NANPASS: how NaN LLRs are handled (Ops<float>::load) -- 0 = in line, by this kernel alone; 1 / 2 = the two passes of the
+// kernel that cannot afford that (the register-lean f32 one: two_pass_nan() in decode_ms_launch.hpp): pass 1 decodes as if no
+// LLR were a NaN and MARKS the codewords that have one (iters_out = NAN_MARK), pass 2 is the in-line kernel over the marked
+// codewords only.
+template <int CODE, class T, int IPT, bool PF, int LEAN, int JW, int FORM, int NANPASS = 0>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
                              uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k, char *lds, char *stage)
@@ -922,11 +930,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN != 2;
     // float LLRs: canonicalise the finished marginals instead of the LLRs (Ops<float>::canon_late) -- the register-lean kernels,
     // which re-read their LLRs in every variable phase, and TM1280 f32
-    constexpr bool LATE_CANON = std::is_floating_point_v<T> && (LEAN != 0 || (CODE == TM1280 && IPT == 1));
+    constexpr bool NONAN = NANPASS == 1;         // first of two passes: NaN LLRs are only looked for (the codeword is marked), not handled
+    constexpr bool REDO = NANPASS == 2;          // second pass: only the codewords the first one marked
+    static_assert(NANPASS == 0 || (std::is_floating_point_v<T> && LEAN == 1 && G == 1 && !PF && GEO::WG > 64), "two-pass NaN handling: the register-lean float kernel, one multi-wave codeword per workgroup");
+    constexpr bool LATE_CANON = std::is_floating_point_v<T> && (LEAN != 0 || (CODE == TM1280 && IPT == 1)) && !NONAN;
     // (Tried for the register-lean f32 kernel, which cannot afford even that -- 45 more spilled registers, TM5120 f32 17.1 ->
     // 14.4 M codewords/s: look for a NaN among a codeword's LLRs once, before the first pass, and run a second copy of the loop
     // that canonicalises only for codewords that have one.  The second copy alone costs more: 120 spilled registers, 13.3 M
-    // codewords/s (LDPC_NANVOTE, kbench only; profiles/r03_kbench/kb16_nanvote.txt).  What is left is DESIGN.md 7 (c).)
+    // codewords/s (LDPC_NANVOTE, kbench only; profiles/r03_kbench/kb16_nanvote.txt).  The vote survives as the MARK of the
+    // two-pass form: the common copy is the whole first kernel, the canonicalising copy a second kernel.)
 #ifdef LDPC_NANVOTE
     constexpr bool NANVOTE = LDPC_NANVOTE != 0 && LATE_CANON && LEAN == 1 && std::is_same_v<T, float> && G == 1;
 #else
@@ -1059,7 +1071,10 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     if constexpr (PACKED_LLR) acc = O::load((T)(llr_pk[S][C / PER_REG] >> (PK_BITS * (C % PER_REG))));
                     else if constexpr (LEAN) {
                         const T x = (llrs + (size_t)(live ? cw : 0) * N)[(unsigned)(C * M) + (unsigned)i];
-                        acc = CANON ? O::keep_raw(x) : (NANVOTE ? O::load_nonan(x) : O::load(x));
+                        // (first of two NaN passes: the raw value here and `+ 0.0` on the finished marginal, as canon_late does it --
+                        // with the `+ 0.0` up here the lean TM5120 kernel spills 53 registers instead of 8)
+                        acc = (CANON || NONAN) ? O::keep_raw(x) : (NANVOTE ? O::load_nonan(x) : O::load(x));
+                        
                     }
                     else acc = llr[S][C];
                 }
@@ -1075,6 +1090,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                         }
                     });
                     if constexpr (CANON && C < NTX) acc = O::canon_late(acc);        // (see Ops<float>::canon_late)
+                    else if constexpr (NONAN && C < NTX) acc = O::load_nonan(acc);
                     if constexpr (col_slot(P, C) < 0) va[S][C] = acc;               // exchanged columns: only the sign word is kept (hi array)
                     static_for<0, NB>([&](auto B_) LDPC_INLINE {                       // nv = va - u (:421), in place
                         constexpr int B = decltype(B_)::value;
@@ -1101,6 +1117,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     }
                 });
                 if constexpr (CANON && C < NTX) acc = O::canon_late(acc);          // (see Ops<float>::canon_late)
+                else if constexpr (NONAN && C < NTX) acc = O::load_nonan(acc);
                 va[S][C] = acc;
                 constexpr int cs = col_slot(P, C);
                 if constexpr (cs >= 0) {
@@ -1474,9 +1491,28 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         }
     };
 
-    if constexpr ((NOCAP_POSSIBLE && GEO::WG != 64) || NANVOTE) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
-    if (blockIdx.x * CLAIM_K < n_groups) fetch_llrs(G == 1 ? blockIdx.x * CLAIM_K : blockIdx.x * CLAIM_K * G + grp);
+    if constexpr ((NOCAP_POSSIBLE && GEO::WG != 64) || NANVOTE || NONAN) { if (t == 0) cap_flag() = 0; LDPC_SYNC(); }
+    // Second NaN pass: workgroup b looks through the groups b, b + gridDim.x, ... for the ones the first pass marked, 64 at a
+    // time (one load per lane, one ballot; every wave of the workgroup computes the same wave-uniform answer).  A launch
+    // without a NaN is a few such loads per workgroup.
+    auto next_marked = [&](uint32_t g0) LDPC_INLINE -> uint32_t {
+        const uint32_t stride = gridDim.x;
+        while (g0 < n_groups) {
+            const uint32_t cand = g0 + (uint32_t)(tid & 63) * stride;           // (n_groups < 2^31 and 64 * stride < 2^20: no wrap)
+            const bool hit = cand < n_groups && iters_out[cand] == NAN_MARK;
+            const unsigned long long m = __ballot(hit);
+            if (m != 0) return g0 + (uint32_t)__builtin_ctzll(m) * stride;
+            g0 += 64u * stride;
+        }
+        return n_groups;
+    };
+    (void)next_marked;
+    if constexpr (!REDO) { if (blockIdx.x * CLAIM_K < n_groups) fetch_llrs(G == 1 ? blockIdx.x * CLAIM_K : blockIdx.x * CLAIM_K * G + grp); }
     uint32_t chunk = blockIdx.x, g = chunk * CLAIM_K, g_end = g + CLAIM_K;       // [g, g_end): the rest of the current chunk
+    if constexpr (REDO) {                        // (the launcher gives the second pass no queue: CLAIM_K = 1)
+        chunk = next_marked(blockIdx.x); g = chunk; g_end = g + 1;
+        if (g < n_groups) fetch_llrs(g);
+    }
     for (uint32_t first = 1; g < n_groups; first = 0) {
     cw = G == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)g) : g * G + grp;
     live = cw < batch;
@@ -1545,12 +1581,20 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     }
 
     // ---- hard decision of the marginals, MSB first (decoder.rs:455-461 / :467-473) ------------
+    // First of two NaN passes: where is a NaN LLR noticed?  At the END, in the marginals: without the NaN mapping a variable's
+    // marginal is NaN after every variable phase exactly if its LLR is (NaN + u stays NaN; nothing else makes one: every u is a
+    // finite +-min(|v|..., maxval) -- v_min ignores NaN operands -- and a finite or infinite LLR plus finite numbers is no NaN),
+    // and the marginals are live here anyway.  (Testing the LLRs where they are loaded -- at the start of the codeword, or in the
+    // lean kernel's first variable phase -- keeps them alive side by side and costs that kernel 45-70 spilled registers.)
+    bool nan_seen = false;
+    (void)nan_seen;
     if constexpr (NT >= 64) {
         unsigned long long w[IPT][NCOLS];
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, C = decltype(C_)::value;
                 const unsigned long long bits = __ballot(marginal_bits(S_, C_) < 0);   // bit l = lane l
+                if constexpr (NONAN && C < NTX) nan_seen |= va[S][C] != va[S][C];
                 const unsigned lo = __builtin_bswap32(__builtin_bitreverse32((unsigned)bits));
                 const unsigned hi = __builtin_bswap32(__builtin_bitreverse32((unsigned)(bits >> 32)));
                 w[S][C] = (unsigned long long)lo | ((unsigned long long)hi << 32);
@@ -1576,13 +1620,21 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             });
         });
     }
-    if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
+    if constexpr (NONAN) {
+        static_assert(!NOCAP_POSSIBLE && !NANVOTE && NT >= 64, "first NaN pass: the clamp-vote word is the mark");
+        if (maxiters != 0 && __ballot(nan_seen) != 0 && (tid & 63) == 0) cap_flag() = 1;       // (zero iterations: no marginal was ever computed, and none depends on an LLR)
+    } else {
+        if (t == 0 && live) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; }
+    }
     if constexpr ((NOCAP_POSSIBLE && GEO::WG != 64) || NANVOTE) { if (t == 0) cap_flag() = 0; }
     if constexpr (!CLAIM_AHEAD) {
         if (dyn && fresh && tid == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         collect_claim();
     }
     LDPC_SYNC();                  // every wave is done with the flags before the next codeword resets them
+    if constexpr (NONAN) {        // the waves' marks are in: results or mark, and the word is clear again long before the next epilogue
+        if (t == 0 && live) { iters_out[cw] = cap_flag() != 0 ? NAN_MARK : iters; success_out[cw] = ok ? 1 : 0; cap_flag() = 0; }
+    }
     // next group: the rest of this chunk, then the claimed chunk (collected during this chunk's first decode, many
     // barriers ago) or the static stride
     ++g;
@@ -1590,6 +1642,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     if (g >= g_end || g >= n_groups) {
         if (dyn) chunk = GEO::WG == 64 ? next_chunk : (uint32_t)__builtin_amdgcn_readfirstlane(*next_word);
         else chunk += gridDim.x;
+        if constexpr (REDO) chunk = next_marked(chunk);
         g = chunk < n_chunks ? chunk * CLAIM_K : n_groups;
         g_end = g + CLAIM_K;
         fresh = true;
@@ -1633,7 +1686,7 @@ constexpr int min_waves_per_simd()
     return 1;
 }
 
-template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM = selfcorr_med3<CODE, T>()>
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM = selfcorr_med3<CODE, T>(), int NANPASS = 0>
 __global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
 decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                  uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
@@ -1651,17 +1704,17 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     // arrivals of the whole workgroup, whichever copy a wave runs).
     if constexpr (LDPC_QUARTER_SPECIALISE && GEO::G == 1 && GEO::NT == 2 * Q && Q >= 64) {
         if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < Q)
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 0, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 0, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
         else
-            decode_ms_body<CODE, T, IPT, PF, LEAN, 1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+            decode_ms_body<CODE, T, IPT, PF, LEAN, 1, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     } else if constexpr (LDPC_QUARTER_SPECIALISE >= 2 && GEO::G == 1 && GEO::NT == 4 * Q && Q >= 64) {
         const int jw = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / Q;
-        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
-        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
-        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
-        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        if (jw == 0) decode_ms_body<CODE, T, IPT, PF, LEAN, 0, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else if (jw == 1) decode_ms_body<CODE, T, IPT, PF, LEAN, 1, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else if (jw == 2) decode_ms_body<CODE, T, IPT, PF, LEAN, 2, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        else decode_ms_body<CODE, T, IPT, PF, LEAN, 3, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     } else {
-        decode_ms_body<CODE, T, IPT, PF, LEAN, -1, FORM>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
+        decode_ms_body<CODE, T, IPT, PF, LEAN, -1, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k, lds, stage);
     }
 }
 

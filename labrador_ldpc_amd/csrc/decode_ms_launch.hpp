@@ -46,8 +46,13 @@ inline float nocap_limit_for(uint32_t maxiters, bool clamp_form = false)
     return (float)__builtin_ldexp(1.0, (int)__builtin_floor(log2_limit));
 }
 
-// `variant` flag: fixed-stride distribution of the codewords (no queue); the rest of `variant` selects the kernel
-constexpr int VARIANT_STATIC = 256;
+// `variant` flags; the rest of `variant` selects the kernel.  VARIANT_STATIC: fixed-stride distribution of the codewords (no
+// queue).  VARIANT_ONE_PASS / VARIANT_TWO_PASS: force the one-kernel / the two-kernel handling of NaN LLRs for the kernels
+// that have both (two_pass_nan() below; by default the batch size decides) -- for tests and A/B timing.
+constexpr int VARIANT_STATIC = 256, VARIANT_ONE_PASS = 512, VARIANT_TWO_PASS = 1024;
+constexpr int VARIANT_FLAGS = VARIANT_STATIC | VARIANT_ONE_PASS | VARIANT_TWO_PASS;
+// the same as launch flags (`lflags`), split off `variant` by LDPC_SPLIT_VARIANT
+constexpr unsigned LF_STATIC = 1, LF_ONE_PASS = 2, LF_TWO_PASS = 4;
 
 // The queue head of a launch's dynamic codeword distribution (decode_ms_body, "dynamic distribution"): a device word that
 // is zero between launches -- the kernel that drew from it puts it back.  One word per (device, stream): launches of a
@@ -87,7 +92,7 @@ inline uint32_t *claim_counter(hipStream_t stream)
 }
 
 // Resident workgroups per device for one instantiation (occupancy x compute units), cached.
-template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM>
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM, int NANPASS = 0>
 int resident_workgroups()
 {
     using GEO = Geometry<CODE, T, IPT>;
@@ -97,7 +102,7 @@ int resident_workgroups()
     int v = cached[dev].load(std::memory_order_relaxed);
     if (v == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM>, GEO::WG, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM, NANPASS>, GEO::WG, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         v = per_cu * cus;
@@ -107,10 +112,11 @@ int resident_workgroups()
 }
 
 // Launch one instantiation (IPT indices per thread; LEAN 1 = register-lean check phase, 2 = in-place messages).
-template <int CODE, class T, int IPT, int LEAN, int FORM>
+template <int CODE, class T, int IPT, int LEAN, int FORM, int NANPASS = 0>
 hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                           size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+                           size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
+    const bool static_stride = (lflags & LF_STATIC) != 0 || NANPASS == 2;     // (the second NaN pass walks its own stride classes)
     using GEO = Geometry<CODE, T, IPT>;
     // LLR staging (PF) is implemented but measured SLOWER than plain loads at the start of each
     // codeword on TM8192 (4.99 vs 5.29 M codewords/s: the extra live state costs spills at the
@@ -130,7 +136,7 @@ hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint
     // the fixed stride: their decodes take tens of microseconds and a workgroup is expensive to start); the fixed stride on
     // the 16x grid for the smaller ones, where the hardware dispatcher is a queue that costs no atomics (the TC codes' draws
     // would hit the device's ceiling of ~85 M same-address atomics per second: claim_chunk()).
-    const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN, FORM>();
+    const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN, FORM, NANPASS>();
     constexpr bool queue_fed = GEO::WG >= 512;
     uint32_t *claim = (static_stride || maxiters == 0 || !queue_fed) ? nullptr : claim_counter(stream);
     // groups per draw: at least ~8 draws per resident workgroup, so that the last chunks are a small part of a short launch
@@ -142,8 +148,11 @@ hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint
     const size_t chunks = (groups + K - 1) / K;
     size_t grid = (resident <= 256 || claim != nullptr) ? resident : resident * 16;
     if (grid > chunks) grid = chunks;
+    if constexpr (NANPASS == 2) {                // one round of workgroups, each looking at 64 marks per load
+        grid = resident < (groups + 63) / 64 ? resident : (groups + 63) / 64;
+    }
     constexpr bool clamp_form = std::is_same_v<T, float> && FORM == 2;
-    hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
+    hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM, NANPASS>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
                        llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim, (uint32_t)K);
     return hipGetLastError();
 }
@@ -153,22 +162,54 @@ hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint
 // codewords/s) narrows the range vote to |LLR| <= 2^floor(82.5 - log2(7) max_iters) -- 2^12 at the benchmark's 25 iterations,
 // 2^3 at 28; beyond that real LLRs would fall out of the clamp-free loop altogether, so longer decodes run the v_mul_legacy
 // form, whose vote is the clamp-free loop's own.
+//
+// NaN LLRs in two passes.  The NaN -> +inf mapping of Ops<float>::load is free in every f32 kernel but one: the register-lean
+// TM5120 kernel re-reads its LLRs in every variable phase and has no register to spare -- canonicalising the finished marginals
+// instead costs it 45 spilled registers, 17.1 -> 14.4 M codewords/s.  Its batches therefore run two kernels on the stream: the
+// first decodes as if no LLR were a NaN -- round 2's loop -- and looks at the marginals it has in registers when a decode ends
+// (a NaN LLR leaves a NaN marginal, nothing else does): for a codeword with one it leaves NAN_MARK in `iters` instead of
+// results.  The second is the NaN-handling kernel restricted to the marked codewords: without a NaN in the batch a few loads per
+// workgroup.  TM5120 f32 14.4 -> 16.9 M codewords/s at 524 288 frames, +5 % still at 1 024; with a NaN in every hundredth frame
+// 16.1 (profiles/r03_kbench/nan_two_pass_ab.txt).  Batches below two rounds of workgroups run the NaN-handling kernel alone, as do
+// max_iters = 0 (nothing depends on the LLRs) and max_iters = 2^32 - 1 (the mark must not be an iteration count).  Results
+// are identical either way (tests/test_gpu_parity.py::test_nan_two_pass).
+// (TM1280 f32, the other kernel that pays for the mapping, gains 3 % from two passes and loses as much once NaNs are present:
+// it keeps the one kernel.)
+template <int CODE, class T, int IPT, int LEAN>
+constexpr bool two_pass_nan()
+{
+    return std::is_same_v<T, float> && IPT == 1 && CODE == TM5120 && LEAN == 1;
+}
+
 template <int CODE, class T, int IPT, int LEAN>
 hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                      size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+                      size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
+    if constexpr (two_pass_nan<CODE, T, IPT, LEAN>()) {
+        constexpr int FORM = selfcorr_med3<CODE, T>();
+        static_assert(!has_nocap_loop<CODE, T, IPT, LEAN>());
+        bool two = batch >= 2 * (size_t)resident_workgroups<CODE, T, IPT, false, LEAN, FORM, 1>();
+        if (lflags & LF_TWO_PASS) two = true;
+        if ((lflags & LF_ONE_PASS) || maxiters == 0 || maxiters == NAN_MARK) two = false;
+        if (two) {
+            const hipError_t e = launch_cfg_form<CODE, T, IPT, LEAN, FORM, 1>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+            if (e != hipSuccess) return e;
+            return launch_cfg_form<CODE, T, IPT, LEAN, FORM, 2>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+        }
+        return launch_cfg_form<CODE, T, IPT, LEAN, FORM>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+    } else
     if constexpr (has_nocap_loop<CODE, T, IPT, LEAN>() && selfcorr_med3<CODE, T>() == 2) {
         if (nocap_limit_for(maxiters, true) >= 8.0f)
-            return launch_cfg_form<CODE, T, IPT, LEAN, 2>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
-        return launch_cfg_form<CODE, T, IPT, LEAN, 3>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+            return launch_cfg_form<CODE, T, IPT, LEAN, 2>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+        return launch_cfg_form<CODE, T, IPT, LEAN, 3>(llrs, output, iters, success, batch, maxiters, stream, lflags);
     } else {
-        return launch_cfg_form<CODE, T, IPT, LEAN, selfcorr_med3<CODE, T>()>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        return launch_cfg_form<CODE, T, IPT, LEAN, selfcorr_med3<CODE, T>()>(llrs, output, iters, success, batch, maxiters, stream, lflags);
     }
 }
 
 template <int CODE, class T, int IPT>
 hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                      size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+                      size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
     // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
     // is TM5120 (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB) and the narrow types of TM1280.  Measured slower
@@ -176,14 +217,14 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // TM1280 i8 / i16: 168 -> 116 VGPRs, four waves per SIMD instead of three: 68.4 -> 71.0 (its f32 kernel 70.5 -> 69.5: not).
     constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
     constexpr int LEAN = (CODE == TM5120 || (CODE == TM1280 && narrow)) && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
-    return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+    return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, lflags);
 }
 
 // Pair-ownership kernel (decode_ms_pair.hpp): one workgroup per CU-resident codeword, persistent.
 constexpr int VARIANT_PAIR = 32;
 template <int CODE, class T, int FORM>
 hipError_t launch_pair_form(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                            size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+                            size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
     using GEO = PairGeometry<CODE, T>;
     static std::atomic<int> cached[64] = {};
@@ -197,7 +238,7 @@ hipError_t launch_pair_form(const T *llrs, uint8_t *output, uint32_t *iters, uin
         resident = per_cu * cus;
         cached[dev].store(resident, std::memory_order_relaxed);
     }
-    uint32_t *claim = (static_stride || maxiters == 0) ? nullptr : claim_counter(stream);
+    uint32_t *claim = ((lflags & LF_STATIC) != 0 || maxiters == 0) ? nullptr : claim_counter(stream);
     size_t grid = (resident <= 256 || claim != nullptr) ? (size_t)resident : (size_t)resident * 16;
     if (grid > batch) grid = batch;
     constexpr bool clamp_form = std::is_same_v<T, float> && FORM == 2;
@@ -208,7 +249,7 @@ hipError_t launch_pair_form(const T *llrs, uint8_t *output, uint32_t *iters, uin
 
 template <int CODE, class T>
 hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                       size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+                       size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
     if (batch == 0) return hipSuccess;
     if (batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
@@ -217,10 +258,10 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
         // benchmark's 25 iterations, 2^3 at 28; beyond that real LLRs would fall out of the clamp-free loop altogether, so longer
         // decodes run the v_mul_legacy form (+7 %), whose vote is the clamp-free loop's own
         if (nocap_limit_for(maxiters, true) >= 8.0f)
-            return launch_pair_form<CODE, T, 2>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
-        return launch_pair_form<CODE, T, 3>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+            return launch_pair_form<CODE, T, 2>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+        return launch_pair_form<CODE, T, 3>(llrs, output, iters, success, batch, maxiters, stream, lflags);
     } else {
-        return launch_pair_form<CODE, T, pair_form_default<T>()>(llrs, output, iters, success, batch, maxiters, stream, static_stride);
+        return launch_pair_form<CODE, T, pair_form_default<T>()>(llrs, output, iters, success, batch, maxiters, stream, lflags);
     }
 }
 
@@ -231,18 +272,23 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
         constexpr int alts[] = {DEF, ##__VA_ARGS__};                                             \
         return dispatch_ipt<CODE, T, DEF, ##__VA_ARGS__>(variant == 0 ? alts[0] : variant, llrs, \
                                                          output, iters, success, batch, maxiters, \
-                                                         stream, static_stride);                 \
+                                                         stream, lflags);                        \
     }
 #define LDPC_SPLIT_VARIANT()                                                                     \
-    const bool static_stride = variant >= 0 && (variant & VARIANT_STATIC) != 0;                  \
-    if (static_stride) variant &= ~VARIANT_STATIC
+    unsigned lflags = 0;                                                                         \
+    if (variant >= 0) {                                                                          \
+        if (variant & VARIANT_STATIC) lflags |= LF_STATIC;                                       \
+        if (variant & VARIANT_ONE_PASS) lflags |= LF_ONE_PASS;                                   \
+        if (variant & VARIANT_TWO_PASS) lflags |= LF_TWO_PASS;                                   \
+        variant &= ~VARIANT_FLAGS;                                                               \
+    }
 
 template <int CODE, class T, int... IPTS>
 hipError_t dispatch_ipt(int ipt, const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
-                        size_t batch, uint32_t maxiters, hipStream_t stream, bool static_stride)
+                        size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
     hipError_t r = hipErrorInvalidConfiguration;
-    (void)((ipt == IPTS ? (r = launch_one<CODE, T, IPTS>(llrs, output, iters, success, batch, maxiters, stream, static_stride), true)
+    (void)((ipt == IPTS ? (r = launch_one<CODE, T, IPTS>(llrs, output, iters, success, batch, maxiters, stream, lflags), true)
                         : false) || ...);
     return r;
 }

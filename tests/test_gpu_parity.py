@@ -113,6 +113,67 @@ def test_f32_corner_values(code):
         _compare(code, llrs, 20, variant=variant)
 
 
+@pytest.mark.parametrize("code", [LDPCCode.TM5120], ids=lambda c: c.name)
+def test_nan_two_pass(code):
+    """The register-lean TM5120 f32 kernel handles NaN LLRs in TWO kernels unless the batch is small (decode_ms_launch.hpp,
+    two_pass_nan()): the first decodes as if there were none and leaves a mark in `iters` for every codeword whose marginals
+    show one, the second is the NaN-handling kernel over the marked codewords.  `variant` 512 / 1024 force one / two passes; the
+    default decides by batch size.  All three must agree with the oracle frame for frame: NaNs of every kind (quiet, signalling,
+    both signs, one per frame, whole frames, next to infinities) at the first, the last and runs of positions of a batch large
+    enough for the default to take two passes; a batch without any; a batch of nothing else; no mark left behind."""
+    import torch
+    rng = np.random.default_rng(0x7A + int(code))
+    n = code.n()
+    clean, _ = oracle.awgn_llrs(code, rng, 24, 3.5, np.float32)
+    clean[0, ::5] = -0.0
+    clean[1, ::7] = np.inf
+    clean[2, ::9] = -np.inf
+    dirty, _ = oracle.awgn_llrs(code, rng, 12, 3.5, np.float32)
+    qp, qn, sp, sn = (np.array([v], dtype=np.uint32) for v in (0x7FC00000, 0xFFC00000, 0x7FA00000, 0xFFA00001))
+    u = dirty.view(np.uint32)
+    for row, pat in enumerate((qp, qn, sp, sn)):
+        u[row, rng.integers(n)] = pat[0]                       # one NaN in the frame
+    for row in range(4, 8):
+        for j, pos in enumerate(rng.permutation(n)[:40]):
+            u[row, pos] = (qp, qn, sp, sn)[j % 4][0]
+    u[8, :] = qn[0]
+    u[9, ::2] = sn[0]
+    dirty[10, ::13] = np.inf
+    u[10, 5::13] = qn[0]
+    u[11, n - 1] = qn[0]                                       # the very last LLR of a frame
+    assert np.isnan(dirty).any(axis=1).all() and not np.isnan(clean).any()
+    base = np.concatenate([clean, dirty])
+    ref = oracle.decode_ms_batch(code, base, 25)
+    nc, nd = len(clean), len(dirty)
+
+    def check(idx, variants):
+        d = torch.from_numpy(base[idx]).cuda()
+        for variant in variants:
+            out, it, ok = (t.cpu().numpy() for t in code.decode_ms_batch(d, 25, variant=variant))
+            bad = np.nonzero((it != ref[1][idx]) | (ok != ref[2][idx]) | (out != ref[0][idx]).any(axis=1))[0]
+            assert bad.size == 0, (code.name, len(idx), variant, bad[:8], it[bad[:8]], ref[1][idx][bad[:8]])
+
+    check(np.arange(len(base)), (512, 1024, 1024 + 256, 0))                               # small batch, every kind of frame
+    check(nc + np.arange(nd), (1024, 512))                                                # nothing but marked codewords
+    check(np.arange(nc), (1024,))                                                         # no NaN anywhere
+    check(np.array([nc + 1]), (1024, 512))                                                # batch of one
+    big = 12000                                                                           # two passes by default
+    idx = rng.integers(0, nc, big)
+    idx[0] = nc                                                                           # first and last codeword of the launch
+    idx[-1] = nc + 11
+    idx[1000:1000 + nd] = nc + np.arange(nd)                                              # a run
+    idx[rng.integers(0, big, 300)] = nc + rng.integers(0, nd, 300)                        # scattered
+    check(idx, (0, 1024, 512, 0))
+    check(rng.integers(0, nc, big), (0,))                                                 # large and clean
+    d = torch.from_numpy(base[idx]).cuda()
+    out, it, ok = (t.cpu().numpy() for t in code.decode_ms_batch(d, 0, variant=1024))     # zero iterations: one pass whatever was asked
+    assert not out.any() and (it == 0).all() and (ok == 0).all()
+    for maxiters in (1, 2):
+        o_c, i_c, k_c, _ = oracle.decode_ms_batch(code, base, maxiters)
+        out, it, ok = (t.cpu().numpy() for t in code.decode_ms_batch(torch.from_numpy(base).cuda(), maxiters, variant=1024))
+        assert (out == o_c).all() and (it == i_c).all() and (ok == k_c).all(), maxiters
+
+
 @pytest.mark.parametrize("code", [LDPCCode.TC128, LDPCCode.TC256, LDPCCode.TC512, LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048,
                                   LDPCCode.TM5120, LDPCCode.TM8192], ids=lambda c: c.name)
 @pytest.mark.parametrize("maxiters", [0, 1, 2, 3])

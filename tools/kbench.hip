@@ -23,6 +23,9 @@
 #ifndef KT
 #define KT float
 #endif
+#ifndef KNANPASS
+#define KNANPASS 0            // decode_ms_body's NANPASS: 1 = the first of the two NaN passes (marks, does not handle), 2 = the second
+#endif
 #ifndef KLEAN
 #define KLEAN false
 #endif
@@ -63,7 +66,7 @@ int main()
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_pair_kernel<code, KT>, PairGeometry<code, KT>::NT, 0));
         const unsigned chunks = groups;
 #else
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>, GEO::WG, 0));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_kernel<code, KT, KIPT, KPF, KLEAN, selfcorr_med3<code, KT>(), KNANPASS>, GEO::WG, 0));
 #ifdef KSTATIC
         const unsigned K = 1, chunks = groups;
 #else
@@ -98,7 +101,7 @@ int main()
 #if KPAIR
         hipLaunchKernelGGL((decode_ms_pair_kernel<code, KT>), dim3(groups), dim3(PairGeometry<code, KT>::NT), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim);
 #else
-        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim, (uint32_t)claim_chunk<code, KT, KIPT>());
+        hipLaunchKernelGGL((decode_ms_kernel<code, KT, KIPT, KPF, KLEAN, selfcorr_med3<code, KT>(), KNANPASS>), dim3(groups), dim3(GEO::WG), 0, 0, llrs, out, iters, ok, (uint32_t)F, (uint32_t)KMAXIT, KLIMIT, claim, (uint32_t)claim_chunk<code, KT, KIPT>());
 #endif
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
