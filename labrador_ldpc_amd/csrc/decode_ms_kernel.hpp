@@ -88,6 +88,19 @@ LDPC_DEV int xor_reduce(const int (&w)[D])
     return acc;
 }
 
+// acc ^ w[0] ^ ... ^ w[N - 1], two words per v_bitop3_b32 (a running `acc ^= w` costs one v_xor per word)
+template <int N, int D>
+LDPC_DEV int xor_into(int acc, const int (&w)[D])
+{
+    static_assert(N <= D);
+    static_for<0, N / 2>([&](auto I_) LDPC_INLINE {
+        constexpr int i = 2 * decltype(I_)::value;
+        acc = __builtin_amdgcn_bitop3_b32(acc, w[i], w[i + 1], 0x96);
+    });
+    if constexpr (N % 2 == 1) acc ^= w[N - 1];
+    return acc;
+}
+
 // ---- prototype analysis -------------------------------------------------------------------
 constexpr bool blk_local(const Block &b) { return b.kind == BLK_I && b.val == 0; }
 constexpr int count_exchanged(const Prototype &p)
@@ -187,6 +200,7 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     LDPC_DEV static float store(R x) { return x; }
     LDPC_DEV static R from_lds(float x) { return x; }                           // already canonical
     LDPC_DEV static int bits(R x) { return __float_as_int(x); }
+    LDPC_DEV static int sign_word(R x) { return __float_as_int(x) & (int)0x80000000; }     // bit 31 of a message, alone
     LDPC_DEV static R add(R a, R b) { return a + b; }                           // :74
     LDPC_DEV static R sub(R a, R b) { return a - b; }                           // :75
     LDPC_DEV static R sub_nv(R a, R b) { return a - b; }                        // the new v of an edge (:421)
@@ -276,6 +290,7 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     template <int FORM>
     LDPC_DEV static R clamp_to_side(R nv, R old, float big)
     {
+        static_assert(FORM == 2 || FORM == 3 || FORM == 5, "clamp forms of the self-correction: 2, 3, 5 (6: integer messages only, IntOps)");
         R x, r;
         if constexpr (FORM == 2) {
             asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "s"(big), "v"(old), "v"(nv));
@@ -354,6 +369,7 @@ template <> struct Ops<double> {
     LDPC_DEV static double store(R x) { return x; }
     LDPC_DEV static R from_lds(double x) { return x; }
     LDPC_DEV static int bits(R x) { return __double2hiint(x); }
+    LDPC_DEV static int sign_word(R x) { return __double2hiint(x) & (int)0x80000000; }
     LDPC_DEV static R add(R a, R b) { return a + b; }
     LDPC_DEV static R sub(R a, R b) { return a - b; }
     LDPC_DEV static R sub_nv(R a, R b) { return a - b; }
@@ -400,6 +416,10 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
     // work; a - b is exact in f32 (|a - b| < 2^17).  One v_med3 less per edge and iteration.
     LDPC_DEV static R sub_nv(R a, R b) { return a - b; }
     LDPC_DEV static R mag(R x) { return __builtin_fminf(__builtin_fabsf(x), (float)HI); }   // saturating_abs
+#ifdef LDPC_SIGN_BY_MUL
+    // bit 31 of an integer message as +-0.0 = 0.0 * x: a float multiply (F class) instead of a v_and (kbench experiment)
+    LDPC_DEV static int sign_word(R x) { float z; asm("v_mul_f32_e32 %0, 0, %1" : "=v"(z) : "v"(x)); return __float_as_int(z); }
+#endif
     // Self-correction test of decoder.rs:422 for integer-valued messages: old != 0 and the signs differ exactly
     // when the product is negative -- |nv|, |old| < 2^17, so the f32 product can neither underflow to zero nor
     // lose its sign (it may round), and nv == 0 gives v = 0 whichever way the test goes.  An F-class v_mul_f32
@@ -413,10 +433,19 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
     }
     // FORM 2 / 3: the clamp forms of Ops<float>::clamp_to_side -- exact for every integer message: |nv| < 2^17 and a
     // nonzero |old| >= 1, so 2^20 * |old| > |nv| always
+    // FORM 6: form 5 without its multiply.  Integer messages are zero or at least 1 in magnitude, so nv * old is <= -1 when
+    // the signs differ, >= 1 when they agree and 0 when either is zero: s = clamp01(fma(nv, old, 1)) is 0 / 1 / 1 with no scale
+    // factor, and v = fma(nv, s, 0).  Two full-rate instructions per update and no 4-cycle one (form 2: fma + med3, form 5:
+    // mul + fma + fma).  The product is below 2^33 and rounds, but never across zero.
     template <int FORM>
     LDPC_DEV static R self_correct(R nv, R old)
     {
-        if constexpr (FORM >= 2) {
+        if constexpr (FORM == 6) {
+            float sel, r;
+            asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(sel) : "v"(nv), "v"(old));
+            asm("v_fma_f32 %0, %1, %2, 0" : "=v"(r) : "v"(nv), "v"(sel));
+            return r;
+        } else if constexpr (FORM >= 2) {
             return Ops<float>::clamp_to_side<FORM>(nv, old, 0x1p20f);
         } else if constexpr (FORM == 1) {
             float p;
@@ -467,6 +496,7 @@ template <> struct Ops<int32_t> {
     LDPC_DEV static float store(R x) { return __int_as_float(x); }
     LDPC_DEV static R from_lds(float x) { return __float_as_int(x); }
     LDPC_DEV static int bits(R x) { return x; }
+    LDPC_DEV static int sign_word(R x) { return x & (int)0x80000000; }
     LDPC_DEV static R add(R a, R b) { R d; asm("v_add_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // :65
     LDPC_DEV static R sub(R a, R b) { R d; asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // :66
     LDPC_DEV static R sub_nv(R a, R b) { return sub(a, b); }                    // (32-bit: the clamp is what keeps it from wrapping)
@@ -600,7 +630,8 @@ template <int CODE, int IPT>
 constexpr int Geometry_G() { return CODES[CODE].m / IPT >= 64 ? 1 : 64 / (CODES[CODE].m / IPT); }      // codewords per workgroup (Geometry::G)
 
 // Form of the self-correction in decode_ms_kernel (Ops<float>::clamp_to_side): 0 = compare / borrow + select, 2 = v_fma +
-// v_med3, 3 = v_mul_legacy + v_add + v_med3, 5 = three full-rate operations and no median.  This is the DEFAULT of the
+// v_med3, 3 = v_mul_legacy + v_add + v_med3, 5 = three full-rate operations and no median, 6 = two (integer messages only:
+// IntOps::self_correct).  This is the DEFAULT of the
 // kernel's FORM template parameter; for the f32 kernels with a clamp-free loop the launcher instantiates 2 and 3 and picks by
 // max_iters (form 2 narrows the range vote: nocap_limit_for()).
 // Same-process A/B (tools/kbench.hip, profiles/r03_kbench/kb11_forms.txt; identical outputs), M codewords/s, forms 0 / 2 / 3 / 5:
@@ -608,13 +639,16 @@ constexpr int Geometry_G() { return CODES[CODE].m / IPT >= 64 ? 1 : 64 / (CODES[
 //   the register-lean kernels (form 0 = the borrow form there): TM5120 i8 4 dB 20.76 / 20.74 / - / 21.08, 2 dB 7.87 / 7.85 / - /
 //   7.98; TM1280 i8 77.96 / - / - / 81.44 -- their chunked check rows like the all-full-rate form best;
 //   f32 (only inside a clamp-free copy of the loop): TM2048 - / 40.29 / 38.23 / 38.19;  TC512 - / 139.96 / 136.63 / 136.80.
+// Form 6 against the best of those on every i8 kernel (profiles/r03_kbench/kb18_form6.txt; identical outputs): TM5120 4 dB
+// 21.90 -> 22.61, 2 dB 8.29 -> 8.58; TM8192 pair kernel 7.78 -> 7.99; TM2048 49.4 -> 51.4; TM1536 63.1 -> 65.9; TM1280 85.6 -> 87.4;
+// TM6144 12.28 -> 12.44; TC512 683 -> 701, TC256 1 128 -> 1 142, TC128 2 155 -> 2 190 (5 dB): the narrow types' default everywhere.
 template <int CODE, class T>
 constexpr int selfcorr_med3()
 {
     if (sizeof(T) > 4 || std::is_same_v<T, int32_t>) return 0;
     if (LDPC_SELFCORR_MED3 >= 0) return LDPC_SELFCORR_MED3;
     constexpr bool narrow = sizeof(T) <= 2;
-    if (narrow) return (CODE == TM5120 || CODE == TM1280) ? 5 : 2;      // (TM5120, TM1280: the register-lean kernels, launch_one)
+    if (narrow) return 6;
     return (CODE == TM2048 || CODE == TC512 || CODE == TM1536) ? 2 : 0;    // f32: the kernels with a clamp-free loop (has_nocap_loop)
 }
 
@@ -1269,7 +1303,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
                     a[J] = v[S][B];                                                    // magnitude taken in exclusive_min
-                    sr[J] = O::bits(v[S][B]) & (int)0x80000000;                        // sign word, :439-441
+                    sr[J] = O::sign_word(v[S][B]);                                     // sign word, :439-441
                     if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
@@ -1320,7 +1354,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
             static_for<0, D>([&](auto J_) LDPC_INLINE {
                 constexpr int J = decltype(J_)::value;
                 constexpr int B = row_block(P, Rw, J);
-                const R un = O::apply_sign(e[J], sgn, O::bits(v[S][B]) & (int)0x80000000);   // :398-405
+                const R un = O::apply_sign(e[J], sgn, O::sign_word(v[S][B]));               // :398-405
                 constexpr int slot = exch_slot(P, B);
                 if constexpr (slot >= 0) {
                     constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
@@ -1343,10 +1377,15 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     constexpr int now = k >= 0 ? prio_rows[k] : 3, before = (step > 0 && k >= 1) ? prio_rows[k - 1] : -1;
                     if constexpr (now != before) LDPC_SETPRIO(now);
                 }
-                int par = 0, sgn = 0;
+                // par: XOR of the marginals' words (bit 31: the check's parity, :445-447); sgnw: XOR of the new v's WHOLE words --
+                // bit 31 is the row's sign product (:439-441), masked once per row instead of once per edge.  Both take two
+                // words per v_bitop3_b32: 4.4 -> 3.5 sign / parity instructions per edge; TM5120 i8 21.12 -> 21.90 M codewords/s at
+                // 4 dB, 7.97 -> 8.29 at 2 dB (profiles/r03_kbench/kb18_form6.txt).
+                int par = 0, sgnw = 0;
                 static_for<0, NCH>([&](auto K_) LDPC_INLINE {
                     constexpr int J0 = decltype(K_)::value * CH, J1 = J0 + CH < D ? J0 + CH : D;
                     R xr[CH], ur[CH];
+                    int xw[CH], vw[CH];
                     static_for<J0, J1>([&](auto J_) LDPC_INLINE {                      // requests
                         constexpr int J = decltype(J_)::value;
                         constexpr int B = row_block(P, Rw, J);
@@ -1368,10 +1407,13 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                         constexpr int B = row_block(P, Rw, J);
                         if constexpr (FIRST) v[S][B] = xr[J - J0];
                         else edge_update(S_, IC<B>{}, xr[J - J0], ur[J - J0], IC<0>{});     // :421-425
-                        par ^= O::bits(xr[J - J0]);                                    // :445-447
-                        sgn ^= O::bits(v[S][B]) & (int)0x80000000;                     // :439-441
+                        xw[J - J0] = O::bits(xr[J - J0]);
+                        vw[J - J0] = O::bits(v[S][B]);
                     });
+                    par = xor_into<J1 - J0>(par, xw);
+                    sgnw = xor_into<J1 - J0>(sgnw, vw);
                 });
+                const int sgn = sgnw & (int)0x80000000;
                 if constexpr (LEAN_VERDICT) sgn_row[S][Rw] = sgn;
                 else finish_row(S_, R_, sgn);
                 par_any |= par;

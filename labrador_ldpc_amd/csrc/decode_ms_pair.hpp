@@ -314,7 +314,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
                     a[J] = v[S][B];
-                    sr[J] = O::bits(v[S][B]) & (int)0x80000000;                        // :439-441
+                    sr[J] = O::sign_word(v[S][B]);                                     // :439-441
                     if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
@@ -502,6 +502,7 @@ template <class T>
 constexpr int pair_form_default()
 {
     if (LDPC_PAIR_SELFCORR_MED3 >= 0) return LDPC_PAIR_SELFCORR_MED3;
+    if (sizeof(T) <= 2) return 6;                // integer messages: two full-rate operations (IntOps::self_correct; i8 7.78 -> 7.99)
     return (sizeof(T) > 4 || std::is_same_v<T, int32_t>) ? 0 : 2;
 }
 
