@@ -416,10 +416,8 @@ template <class I, int LO, int HI> struct IntOps : Ops<float> {     // decoder.r
     // work; a - b is exact in f32 (|a - b| < 2^17).  One v_med3 less per edge and iteration.
     LDPC_DEV static R sub_nv(R a, R b) { return a - b; }
     LDPC_DEV static R mag(R x) { return __builtin_fminf(__builtin_fabsf(x), (float)HI); }   // saturating_abs
-#ifdef LDPC_SIGN_BY_MUL
-    // bit 31 of an integer message as +-0.0 = 0.0 * x: a float multiply (F class) instead of a v_and (kbench experiment)
-    LDPC_DEV static int sign_word(R x) { float z; asm("v_mul_f32_e32 %0, 0, %1" : "=v"(z) : "v"(x)); return __float_as_int(z); }
-#endif
+    // (the sign word of an integer message as 0.0 * x = +-0.0 -- a float multiply instead of a v_and -- measures 0 to -2 %:
+    // profiles/r03_kbench/kb19_sign_by_mul.txt)
     // Self-correction test of decoder.rs:422 for integer-valued messages: old != 0 and the signs differ exactly
     // when the product is negative -- |nv|, |old| < 2^17, so the f32 product can neither underflow to zero nor
     // lose its sign (it may round), and nv == 0 gives v = 0 whichever way the test goes.  An F-class v_mul_f32
