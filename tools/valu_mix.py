@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 name = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 tmp = tempfile.mkdtemp()
-subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", os.path.join(ROOT, "build/csrc/decode_ms_f32.o"), "/dev/null"])
+subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", os.path.join(ROOT, "build/csrc/decode_ms_f32_part_1.o"), "/dev/null"])
 subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat", f"--output={tmp}/co", "--unbundle"])
 dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", f"{tmp}/co"], text=True).split("\n")
 cur, body = None, []          # (address, text, branch target or None)
