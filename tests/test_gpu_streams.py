@@ -166,6 +166,44 @@ def test_device_calls_can_be_captured_in_a_hip_graph():
         assert (out.cpu().numpy() == ref[0]).all() and (it.cpu().numpy() == ref[1]).all() and (ok.cpu().numpy() == ref[2]).all()
 
 
+def test_two_pass_nan_decode_in_a_hip_graph_and_in_slices(monkeypatch):
+    """TM5120 f32 above 1 024 frames is TWO launches per call (decode_ms_launch.hpp, two_pass_nan(): a NaN-blind kernel that
+    marks, then the NaN-handling kernel over the marked codewords).  Both are plain stream work: captured into a HIP graph and
+    replayed they reproduce the oracle, NaN frames included, and so do the slices of a batch larger than one launch."""
+    code = LDPCCode.TM5120
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(23)
+    base, _ = oracle.awgn_llrs(code, rng, 48, 3.6, np.float32)
+    base.view(np.uint32)[40:, 7] = 0xFFC00000                  # eight frames with a (negative, quiet) NaN LLR
+    base.view(np.uint32)[44:, ::3] = 0x7FA00000                # four of them mostly signalling NaNs
+    ref = oracle.decode_ms_batch(code, base, 25)
+    frames = 1536
+    idx = rng.integers(0, len(base), frames)
+    idx[0], idx[-1] = 47, 40
+    llrs = torch.from_numpy(base[idx]).to(dev)
+    out = torch.empty((frames, code.output_len()), dtype=torch.uint8, device=dev)
+    it = torch.empty((frames,), dtype=torch.int32, device=dev)
+    ok = torch.empty((frames,), dtype=torch.uint8, device=dev)
+
+    def check():
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == ref[0][idx]).all() and (it.cpu().numpy() == ref[1][idx]).all() and (ok.cpu().numpy() == ref[2][idx]).all()
+
+    code.decode_ms_batch(llrs, 25, output=out, iters=it, success=ok)
+    check()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        code.decode_ms_batch(llrs, 25, output=out, iters=it, success=ok)
+    for _ in range(3):
+        out.zero_(); it.fill_(-1); ok.zero_()                  # (-1 = the mark itself: a stale one must not survive)
+        g.replay()
+        check()
+    monkeypatch.setenv("LABRADOR_LDPC_HIP_MAX_LAUNCH", "1100")  # slices of 1100 and 436 frames: two passes, then one
+    out.zero_(); it.fill_(-1); ok.zero_()
+    code.decode_ms_batch(llrs, 25, output=out, iters=it, success=ok)
+    check()
+
+
 def test_device_batches_larger_than_one_launch_are_sliced(monkeypatch):
     """The kernels take 32-bit frame counts; a device-resident batch is enqueued as launches of at most 2^30
     frames (no size_t batch may be truncated).  The slice is lowered here so that a small batch
