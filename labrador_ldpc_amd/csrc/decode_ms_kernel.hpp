@@ -1614,8 +1614,12 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
     LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
     if constexpr (NOCAP_POSSIBLE || NANVOTE) {
+#ifdef LDPC_DIAG_NOCAP_ONLY
+        iterate(IC<0>{});             // (timing diagnostic: the clamp-free copy of the loop alone -- what would a two-kernel split of the clamp modes buy?)
+#else
         if (GEO::WG == 64 ? cap_wave : __builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
         else iterate(IC<0>{});
+#endif
     } else {
         iterate(IC<1>{});
     }

@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH) || defined(LDPC_DIAG_NOCAP_ONLY)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
