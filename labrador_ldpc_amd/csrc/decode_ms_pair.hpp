@@ -358,7 +358,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     // Where the next codeword's LLR loads are issued: before this one's epilogue (f32: 7.35 -> 7.66 M codewords/s, the
     // epilogue covers part of their latency) or at the top of its own turn (i8 / i16: the early loads' raw bytes are
     // spilled across the epilogue at the 128-register budget -- which also waits for them on the spot -- 48 spilled
-    // registers against 3, 6.99 -> 7.09).  LDPC_PAIR_FETCH_EARLY: -1 = per type, 0 / 1 = force.
+    // registers against 3, 6.99 -> 7.09; fetching a column's two adjacent narrow LLRs with ONE load into ONE register halves
+    // what the early fetch keeps alive, and still spills 23 registers against 6: 8.00 -> 7.71, profiles/r03_kbench/
+    // kb22_pair_packed_fetch.txt).  LDPC_PAIR_FETCH_EARLY: -1 = per type, 0 / 1 = force.
     constexpr bool FETCH_EARLY = LDPC_PAIR_FETCH_EARLY >= 0 ? LDPC_PAIR_FETCH_EARLY != 0 : sizeof(T) >= 4;
     if (FETCH_EARLY && blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
 #ifdef LDPC_DIAG_STAMPS
