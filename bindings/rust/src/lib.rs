@@ -46,6 +46,10 @@ pub const DEVICE_CURRENT: c_int = -1;
 pub const DEVICE_ALL: c_int = -2;
 /// `opts.variant` flag: fixed-stride distribution of the codewords instead of the launch's queue.
 pub const VARIANT_STATIC: c_int = 256;
+/// `opts.variant` flags: force the one-launch / the two-launch handling of NaN LLRs on the kernel that has both
+/// (TM5120 f32; by default the batch size decides).  Results are identical.
+pub const VARIANT_ONE_PASS: c_int = 512;
+pub const VARIANT_TWO_PASS: c_int = 1024;
 
 /// `struct labrador_ldpc_hip_opts`.  `struct_size` makes the struct growable: the library reads a field only if it lies
 /// inside the first `struct_size` bytes.  Use [`HipOpts::new`].
