@@ -182,18 +182,25 @@ struct HostOut { void *host; size_t bytes_per_item; };
 // Small calls (the reference-shaped single-frame entry points above all) go through one pinned host
 // buffer per thread: one copy in, one copy out of a single device block holding all outputs, instead of
 // four pageable copies -- the call's latency is mostly copy and synchronisation overhead.
+// The smallest calls (a frame or a few: DIRECT_CALL_BYTES) skip the copies as well: the kernel reads its input from the pinned
+// buffer and writes its results into it across the link -- a launch and a synchronisation instead of copy, launch, copy,
+// synchronisation (one frame through the reference-shaped entry, TC128 f32: 21.3 -> 17.4 us per call, TM8192 f32 58.4 -> 51.8:
+// profiles/r03_final/single_frame_latency.txt).  The buffer is mapped into every device's address space for that
+// (`dev` is its device-side address); kernels that read their input more than once (the register-lean f32 / f64 decoders
+// re-read their LLRs in every iteration) still get it copied.  LABRADOR_LDPC_HIP_NO_DIRECT=1 keeps the copies.
 struct PinnedStage {
-    void *p = nullptr;
+    void *p = nullptr, *dev = nullptr;
     size_t cap = 0;
     ~PinnedStage() { if (p) (void)hipHostFree(p); }
     hipError_t get(size_t bytes, void **out)
     {
         if (cap < bytes) {
             if (p) (void)hipHostFree(p);
-            p = nullptr; cap = 0;
+            p = nullptr; dev = nullptr; cap = 0;
             const size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
-            hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped);
             if (e != hipSuccess) { p = nullptr; return e; }
+            if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
             cap = want;
         }
         *out = p;
@@ -201,7 +208,12 @@ struct PinnedStage {
     }
 };
 thread_local PinnedStage g_pinned;
-constexpr size_t SMALL_CALL_BYTES = 1u << 20;
+constexpr size_t SMALL_CALL_BYTES = 1u << 20, DIRECT_CALL_BYTES = 64u << 10;
+bool direct_calls_enabled()
+{
+    static const bool off = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_NO_DIRECT"); return e && *e && *e != '0'; }();
+    return !off;
+}
 
 // frames per chunk: about 128 MB of input, at least 8192 frames (the persistent kernels want
 // tens of codewords per workgroup), at most 262144
@@ -219,9 +231,10 @@ size_t chunk_items(size_t in_bytes_per_item)
 }
 
 // launch(d_in, d_out[NOUT], first_item, n_items, stream) -> status code (0 = ok, error text set by the callee)
+// (direct_in: the kernel reads every input byte once, so the smallest calls may let it read the pinned buffer itself)
 template <int NOUT, class Launch>
 int host_pipeline(const void *in, size_t in_bytes_per_item, const HostOut (&outs)[NOUT], size_t items,
-                  hipStream_t user_stream, Launch launch)
+                  hipStream_t user_stream, Launch launch, bool direct_in = false)
 {
     static_assert(NOUT >= 1 && NOUT <= 3, "two staging sets of 1 + NOUT buffers share the 8 pool slots");
     {   // small call: pinned staging, one device block for all outputs
@@ -232,15 +245,21 @@ int host_pipeline(const void *in, size_t in_bytes_per_item, const HostOut (&outs
         if (in_pad + out_off[NOUT] <= SMALL_CALL_BYTES) {
             void *hbuf = nullptr, *dbuf_in = nullptr, *dbuf_out = nullptr;
             HIP_TRY(g_pinned.get(in_pad + out_off[NOUT], &hbuf));
-            HIP_TRY(g_pool.get(0, in_pad, &dbuf_in));
-            HIP_TRY(g_pool.get(1, out_off[NOUT], &dbuf_out));
             char *h_in = static_cast<char *>(hbuf), *h_out = h_in + in_pad;
             std::memcpy(h_in, in, in_total);
-            HIP_TRY(hipMemcpyAsync(dbuf_in, h_in, in_total, hipMemcpyHostToDevice, user_stream));
+            const bool direct = in_pad + out_off[NOUT] <= DIRECT_CALL_BYTES && g_pinned.dev != nullptr && direct_calls_enabled();
+            char *const dev_in = static_cast<char *>(g_pinned.dev), *const dev_out = dev_in + in_pad;
+            if (!(direct && direct_in)) {
+                HIP_TRY(g_pool.get(0, in_pad, &dbuf_in));
+                HIP_TRY(hipMemcpyAsync(dbuf_in, h_in, in_total, hipMemcpyHostToDevice, user_stream));
+            } else {
+                dbuf_in = dev_in;
+            }
+            if (!direct) HIP_TRY(g_pool.get(1, out_off[NOUT], &dbuf_out));
             void *d_outs[NOUT];
-            for (int o = 0; o < NOUT; ++o) d_outs[o] = static_cast<char *>(dbuf_out) + out_off[o];
+            for (int o = 0; o < NOUT; ++o) d_outs[o] = (direct ? dev_out : static_cast<char *>(dbuf_out)) + out_off[o];
             if (int st = launch(dbuf_in, d_outs, (size_t)0, items, user_stream)) return st;
-            HIP_TRY(hipMemcpyAsync(h_out, dbuf_out, out_off[NOUT], hipMemcpyDeviceToHost, user_stream));
+            if (!direct) HIP_TRY(hipMemcpyAsync(h_out, dbuf_out, out_off[NOUT], hipMemcpyDeviceToHost, user_stream));
             HIP_TRY(hipStreamSynchronize(user_stream));
             for (int o = 0; o < NOUT; ++o) std::memcpy(outs[o].host, h_out + out_off[o], items * outs[o].bytes_per_item);
             return LABRADOR_LDPC_HIP_OK;
@@ -573,6 +592,18 @@ int run_sharded(const std::vector<int> &devs, size_t items, int variant, Run run
     return status;
 }
 
+// Does the decoder the launcher will pick read each LLR from memory exactly once?  The register-lean kernels without packed
+// LLRs re-read them in every variable phase (decode_ms_launch.hpp launch_one: TM5120 f32; decode_ms_f64.hip: the tuned f64
+// variants from TM2048 up); an explicit variant is not second-guessed.
+template <class T>
+bool reads_llrs_once(int code, int variant)
+{
+    if (variant != 0) return false;
+    if (std::is_same_v<T, double>) return code < ldpc::TM2048;
+    if (std::is_same_v<T, float>) return code != ldpc::TM5120;
+    return true;
+}
+
 template <class T>
 int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
                  size_t batch, size_t max_iters, const labrador_ldpc_hip_opts *opts)
@@ -621,7 +652,7 @@ int decode_batch(int code, const T *llrs, uint8_t *output, uint32_t *iters, uint
             return fail(LABRADOR_LDPC_HIP_EUNSUPPORTED, "kernel variant %d not built for code %d", variant, code);
         if (e != hipSuccess) return fail(LABRADOR_LDPC_HIP_ERUNTIME, "kernel launch: %s", hipGetErrorString(e));
         return LABRADOR_LDPC_HIP_OK;
-    });
+    }, reads_llrs_once<T>(code, variant));
 }
 
 // The reference-shaped single-frame calls can only say `false` when the library could not run at all (no GPU, a HIP failure,
