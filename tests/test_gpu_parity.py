@@ -80,6 +80,33 @@ def test_saturating_i8(code):
     _compare(code, llrs, 20)
 
 
+@pytest.mark.parametrize("code", ALL, ids=lambda c: c.name)
+@pytest.mark.parametrize("dtype", [np.int8, np.int16], ids=["i8", "i16"])
+def test_integer_self_correction_at_the_ends_of_the_range(code, dtype):
+    """The narrow types' self-correction is v = fma(nv, clamp01(fma(nv, old, 1)), 0) (IntOps::self_correct, form 6): exact because
+    an integer product is 0 or at least 1 in magnitude and never rounds across zero -- up to |nv| < 2^17 times |old| <= 2^15,
+    above 2^24, where the product itself does round.  Frames that live at those ends: full-scale LLRs of random sign (every
+    message saturates: i16 products around 2^31), full scale mixed with zeros and +-1 (the smallest nonzero messages against the
+    largest), noisy frames scaled to clip at the type's limits, 50 iterations so that failing frames keep oscillating; every
+    kernel variant of the code."""
+    info = np.iinfo(dtype)
+    rng = np.random.default_rng(0xF6 + int(code) + info.bits)
+    frames = 24 if code.n() >= 5120 else 64
+    n = code.n()
+    full = np.where(rng.random((frames, n)) < 0.5, info.max, info.min).astype(dtype)
+    mixed = full.copy()
+    r = rng.random((frames, n))
+    mixed[r < 0.25] = 0
+    mixed[(r >= 0.25) & (r < 0.4)] = 1
+    mixed[(r >= 0.4) & (r < 0.55)] = -1
+    noisy, _ = oracle.awgn_llrs(code, rng, frames, 2.0 if code.n() > 1280 else 4.0, dtype, scale=info.max / 1.5, lim=info.max)
+    noisy[noisy == -info.max] = info.min
+    variants = {LDPCCode.TM8192: (0, 2), LDPCCode.TM1536: (0, 2), LDPCCode.TM6144: (0, 2)}.get(code, (0,))
+    for llrs in (full, mixed, noisy):
+        for variant in variants:
+            _compare(code, llrs, 50, variant=variant)
+
+
 @pytest.mark.parametrize("code", [LDPCCode.TC256, LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM5120, LDPCCode.TM8192], ids=lambda c: c.name)
 def test_f32_corner_values(code):
     """Zeros, signed zeros, denormals, huge and infinite LLRs.  (TM1280 / TM1536 / TM5120 take the self-correction
