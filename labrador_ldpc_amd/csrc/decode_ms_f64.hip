@@ -184,7 +184,9 @@ hipError_t launch_decode_ms<double>(int code, int variant, const double *llrs, u
     if (!valid_code(code)) return hipErrorInvalidValue;
     if (variant >= 0) variant &= ~VARIANT_FLAGS;           // (the f64 kernels always draw from the launch's queue)
     if (variant == 0) {
-        static constexpr int tuned[NUM_CODES] = {1, 1, 1, 1, 1, 17, 17, 33, 34};
+        // (re-measured on round 3's kernels, tools/f64_variants.py, M codewords/s: TM1280 plain 18.2 / lean 25.6 / in place 21.3;
+        // TM6144 in place 3.37 / lean 4.04 / lean with two indices 3.82; TM1536 plain 19.5 = lean 19.4; the TC codes plain)
+        static constexpr int tuned[NUM_CODES] = {1, 1, 1, 17, 1, 17, 17, 17, 34};
         variant = tuned[code];
     }
     if (variant != 100)

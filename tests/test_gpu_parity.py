@@ -286,9 +286,9 @@ def test_f64_corner_values(code):
     _compare(code, llrs, 20, variant=100)
 
 
-F64_VARIANTS = [(LDPCCode.TC128, 17), (LDPCCode.TC256, 17), (LDPCCode.TC512, 17), (LDPCCode.TM1280, 17), (LDPCCode.TM1280, 33),
+F64_VARIANTS = [(LDPCCode.TC128, 17), (LDPCCode.TC256, 17), (LDPCCode.TC512, 17), (LDPCCode.TM1280, 1), (LDPCCode.TM1280, 33),
                 (LDPCCode.TM1536, 17), (LDPCCode.TM2048, 1), (LDPCCode.TM2048, 33), (LDPCCode.TM5120, 18), (LDPCCode.TM5120, 33),
-                (LDPCCode.TM6144, 17), (LDPCCode.TM6144, 18), (LDPCCode.TM6144, 2), (LDPCCode.TM8192, 36)]
+                (LDPCCode.TM6144, 33), (LDPCCode.TM6144, 18), (LDPCCode.TM6144, 2), (LDPCCode.TM8192, 36)]
 
 
 @pytest.mark.parametrize("code,variant", F64_VARIANTS + [(c, 100) for c in ALL], ids=lambda v: getattr(v, "name", str(v)))

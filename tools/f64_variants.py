@@ -5,8 +5,8 @@ sys.path.insert(0, ".")
 from labrador_ldpc_amd import LDPCCode, LdpcHipError
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(3)
-CASES = {"TC128": (5.0, 262144), "TC256": (5.0, 262144), "TC512": (5.0, 131072), "TM1280": (4.0, 65536), "TM1536": (3.0, 65536),
-         "TM2048": (3.0, 32768), "TM5120": (4.0, 16384), "TM6144": (3.0, 16384), "TM8192": (2.0, 16384)}
+CASES = {"TC128": (5.0, 262144), "TC256": (5.0, 262144), "TC512": (5.0, 131072), "TM1280": (4.0, 209715), "TM1536": (3.0, 174762),
+         "TM2048": (3.0, 131072), "TM5120": (4.0, 52428), "TM6144": (3.0, 43690), "TM8192": (2.0, 16384)}
 for name, (eb, frames) in CASES.items():
     code = LDPCCode[name]
     data = rng.integers(0, 256, size=(256, code.k() // 8), dtype=np.uint8)
@@ -20,7 +20,9 @@ for name, (eb, frames) in CASES.items():
             out = code.decode_ms_batch(f64, 25, variant=variant); torch.cuda.synchronize()
         except LdpcHipError:
             continue
-        t = time.perf_counter(); out = code.decode_ms_batch(f64, 25, variant=variant); torch.cuda.synchronize(); dt = time.perf_counter() - t
+        dt = 1e9
+        for _ in range(4):                       # best of four
+            t = time.perf_counter(); out = code.decode_ms_batch(f64, 25, variant=variant); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t)
         if ref is None:
             ref = out
         same = all(torch.equal(a, b) for a, b in zip(out, ref))
