@@ -593,14 +593,14 @@ int run_sharded(const std::vector<int> &devs, size_t items, int variant, Run run
 }
 
 // Does the decoder the launcher will pick read each LLR from memory exactly once?  The register-lean kernels without packed
-// LLRs re-read them in every variable phase (decode_ms_launch.hpp launch_one: TM5120 f32; decode_ms_f64.hip: the tuned f64
+// LLRs re-read them in every variable phase (decode_ms_launch.hpp launch_one: TM5120 and TM1280 f32; decode_ms_f64.hip: the tuned f64
 // variants of the TM codes); an explicit variant is not second-guessed.
 template <class T>
 bool reads_llrs_once(int code, int variant)
 {
     if (variant != 0) return false;
     if (std::is_same_v<T, double>) return code <= ldpc::TC512;
-    if (std::is_same_v<T, float>) return code != ldpc::TM5120;
+    if (std::is_same_v<T, float>) return code != ldpc::TM5120 && code != ldpc::TM1280;
     return true;
 }
 

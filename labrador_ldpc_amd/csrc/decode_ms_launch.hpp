@@ -215,8 +215,14 @@ hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     // is TM5120 (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB) and the narrow types of TM1280.  Measured slower
     // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
     // TM1280 i8 / i16: 168 -> 116 VGPRs, four waves per SIMD instead of three: 68.4 -> 71.0 (its f32 kernel 70.5 -> 69.5: not).
+    // Re-measured on round 3's kernels (the lean check phase lost 70 VALU instructions per thread and iteration this round:
+    // profiles/r03_kbench/kb27_lean_again.txt), lean against plain, M codewords/s: TM1280 f32 69.97 -> 74.48 (115 instead of 168
+    // registers: 8 workgroups per CU instead of 6); TM2048 i8 51.47 -> 53.80 (64 instead of 80: 4 instead of 3); TM1536 i8
+    // 65.84 -> 67.88 (5 instead of 4); still slower where it does not buy occupancy: TM1536 f32 69.3 -> 57.7, TM2048 f32 40.2 ->
+    // 31.0, TM6144 f32 11.94 -> 9.68, i8 12.41 -> 11.79.
     constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
-    constexpr int LEAN = (CODE == TM5120 || (CODE == TM1280 && narrow)) && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
+    constexpr bool lean_code = CODE == TM5120 || (CODE == TM1280 && (narrow || std::is_same_v<T, float>)) || ((CODE == TM1536 || CODE == TM2048) && narrow);
+    constexpr int LEAN = lean_code && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
     return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, lflags);
 }
 
