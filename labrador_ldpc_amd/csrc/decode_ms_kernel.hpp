@@ -707,9 +707,7 @@ constexpr uint32_t claim_chunk()
 #ifdef LDPC_CLAIM_K
     return LDPC_CLAIM_K;
 #else
-    // (TM1280 / TM1536: workgroups of two / four waves, 65-90 M codewords/s -- eight groups per draw keep them an order of
-    // magnitude under the ceiling)
-    return (CODE == TM1280 || CODE == TM1536) ? 8 : CODE == TM2048 ? 4 : (CODE == TM5120 || CODE == TM6144) ? 2 : 1;
+    return CODE == TM2048 ? 4 : (CODE == TM5120 || CODE == TM6144) ? 2 : 1;
 #endif
 }
 

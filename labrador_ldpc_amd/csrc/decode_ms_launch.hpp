@@ -136,13 +136,8 @@ hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint
     // the fixed stride: their decodes take tens of microseconds and a workgroup is expensive to start); the fixed stride on
     // the 16x grid for the smaller ones, where the hardware dispatcher is a queue that costs no atomics (the TC codes' draws
     // would hit the device's ceiling of ~85 M same-address atomics per second: claim_chunk()).
-    // Workgroups of two and four waves (TM1280, TM1536) draw from the queue too once a launch is at least eight rounds of them:
-    // TM1536 f32 67.6 -> 69.4-70.0, i8 66.1 -> 68.0, TM1280 f32 73.1 -> 74.5, i8 86.9 -> 87.5 M codewords/s at 1 048 576 frames,
-    // +1...5 % from 32 768 frames up -- and -11 % at 8 192 (TM1280 i8: four codewords per workgroup), where they keep the stride
-    // (profiles/r03_kbench/kb30_queue_small_wg.txt, kb31_queue_small_wg_short.txt).
     const size_t resident = (size_t)resident_workgroups<CODE, T, IPT, PF, LEAN, FORM, NANPASS>();
-    constexpr bool queue_always = GEO::WG >= 512, queue_when_long = GEO::WG >= 128 && GEO::G == 1;
-    const bool queue_fed = queue_always || (queue_when_long && groups >= 8 * resident);
+    constexpr bool queue_fed = GEO::WG >= 512;
     uint32_t *claim = (static_stride || maxiters == 0 || !queue_fed) ? nullptr : claim_counter(stream);
     // groups per draw: at least ~8 draws per resident workgroup, so that the last chunks are a small part of a short launch
     size_t K = 1;
