@@ -14,4 +14,5 @@ python3 -m labrador_ldpc_amd.perftest --code TM8192 --noise ebn0 --snrs $S --max
 python3 -m labrador_ldpc_amd.perftest --code TM2048 --noise ebn0 --snrs $S --max-bits 1e9 --max-errors 50000 > $O/ber_TM2048.ebn0.csv 2>> $O/ber.err
 python3 -m labrador_ldpc_amd.perftest --code TC512 --noise ebn0 --snrs $S --max-bits 1e9 --max-errors 50000 > $O/ber_TC512.ebn0.csv 2>> $O/ber.err
 cmp $O/ber_TM8192.ebn0.csv profiles/r01_ber/TM8192.ebn0.csv && cmp $O/ber_TM2048.ebn0.csv profiles/r01_ber/TM2048.ebn0.csv && cmp $O/ber_TC512.ebn0.csv profiles/r01_ber/TC512.ebn0.csv && echo "BER sweeps (TM8192, TM2048, TC512) byte-identical to profiles/r01_ber" > $O/ber_regression.txt || echo "BER sweeps DIFFER from profiles/r01_ber" > $O/ber_regression.txt
+bash tools/ber_regression_r02.sh >> $O/ber_regression.txt 2>&1          # the other six codes against profiles/r02_ber
 cat $O/ber_regression.txt; tail -2 $O/big_soak.txt; tail -3 $O/rates_all_codes.txt
