@@ -47,7 +47,7 @@ pub const DEVICE_ALL: c_int = -2;
 /// `opts.variant` flag: fixed-stride distribution of the codewords instead of the launch's queue.
 pub const VARIANT_STATIC: c_int = 256;
 /// `opts.variant` flags: force the one-launch / the two-launch handling of NaN LLRs on the kernel that has both
-/// (TM5120 f32; by default the batch size decides).  Results are identical.
+/// (TM5120 f32, TM1280 f32; by default the batch size decides).  Results are identical.
 pub const VARIANT_ONE_PASS: c_int = 512;
 pub const VARIANT_TWO_PASS: c_int = 1024;
 

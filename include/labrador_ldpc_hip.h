@@ -251,7 +251,7 @@ struct labrador_ldpc_hip_opts {
                          it returns after the results are in the host buffers. */
     int   variant;    /* kernel variant; 0 = the tuned default (others: see DESIGN.md / INTEGRATION.md; flags that may be
                          OR-ed in: 256 = fixed-stride distribution of the codewords, 512 / 1024 = one / two launches for
-                         the NaN handling of TM5120 f32).  Every variant returns identical results. */
+                         the NaN handling of TM5120 / TM1280 f32).  Every variant returns identical results. */
     int   n_devices;  /* > 0: shard a MEM_HOST batch over devices[0 .. n_devices) (`device` is ignored) */
     const int *devices; /* HIP ordinals; an ordinal may repeat (that many host pipelines on it) */
 };

@@ -959,7 +959,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
 
     // Iteration 0 as a pass of its own (see check_phase): per kernel, peel_first_default()
-    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : peel_first_default<CODE, T, IPT>()) && LEAN != 2;
+    // (the NaN-blind first pass of TM1280 f32 is the one form of that kernel the peeled pass pays on: 75.4 -> 78.5 M codewords/s)
+    constexpr bool PEEL_FIRST = (LDPC_PEEL_FIRST >= 0 ? LDPC_PEEL_FIRST != 0 : (peel_first_default<CODE, T, IPT>() || (NANPASS == 1 && CODE == TM1280))) && LEAN != 2;
     // float LLRs: canonicalise the finished marginals instead of the LLRs (Ops<float>::canon_late) -- the register-lean kernels,
     // which re-read their LLRs in every variable phase, and TM1280 f32
     constexpr bool NONAN = NANPASS == 1;         // first of two passes: NaN LLRs are only looked for (the codeword is marked), not handled

@@ -173,12 +173,15 @@ hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint
 // 16.1 (profiles/r03_kbench/nan_two_pass_ab.txt).  Batches below two rounds of workgroups run the NaN-handling kernel alone, as do
 // max_iters = 0 (nothing depends on the LLRs) and max_iters = 2^32 - 1 (the mark must not be an iteration count).  Results
 // are identical either way (tests/test_gpu_parity.py::test_nan_two_pass).
-// (TM1280 f32, the other kernel that pays for the mapping, gains 3 % from two passes and loses as much once NaNs are present:
-// it keeps the one kernel.)
+// TM1280 f32 -- on the register-lean kernel since the same round -- does the same: its NaN-blind first pass also takes the peeled
+// first iteration (which the NaN-handling form cannot afford): 72.9 -> 77.0 M codewords/s at 1 048 576 frames, +3 % still at
+// 4 096.  The price is paid by batches that DO hold NaNs, whose marked codewords are a sparse second launch: with one in
+// every hundredth frame 59.2 against 68.0 at 65 536 frames, 71.5 against 72.3 at 1 048 576 (TM5120: 16.1 against 14.3 -- still
+// ahead).  NaN LLRs are a defect upstream of a decoder, not a workload; the common case gets the 5 %.
 template <int CODE, class T, int IPT, int LEAN>
 constexpr bool two_pass_nan()
 {
-    return std::is_same_v<T, float> && IPT == 1 && CODE == TM5120 && LEAN == 1;
+    return std::is_same_v<T, float> && IPT == 1 && (CODE == TM5120 || CODE == TM1280) && LEAN == 1;
 }
 
 template <int CODE, class T, int IPT, int LEAN>

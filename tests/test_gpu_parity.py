@@ -140,9 +140,9 @@ def test_f32_corner_values(code):
         _compare(code, llrs, 20, variant=variant)
 
 
-@pytest.mark.parametrize("code", [LDPCCode.TM5120], ids=lambda c: c.name)
+@pytest.mark.parametrize("code", [LDPCCode.TM5120, LDPCCode.TM1280], ids=lambda c: c.name)
 def test_nan_two_pass(code):
-    """The register-lean TM5120 f32 kernel handles NaN LLRs in TWO kernels unless the batch is small (decode_ms_launch.hpp,
+    """The register-lean f32 kernels (TM5120, TM1280) handle NaN LLRs in TWO kernels unless the batch is small (decode_ms_launch.hpp,
     two_pass_nan()): the first decodes as if there were none and leaves a mark in `iters` for every codeword whose marginals
     show one, the second is the NaN-handling kernel over the marked codewords.  `variant` 512 / 1024 force one / two passes; the
     default decides by batch size.  All three must agree with the oracle frame for frame: NaNs of every kind (quiet, signalling,
@@ -184,7 +184,7 @@ def test_nan_two_pass(code):
     check(nc + np.arange(nd), (1024, 512))                                                # nothing but marked codewords
     check(np.arange(nc), (1024,))                                                         # no NaN anywhere
     check(np.array([nc + 1]), (1024, 512))                                                # batch of one
-    big = 12000                                                                           # two passes by default
+    big = 12000 if code == LDPCCode.TM5120 else 40000                                     # two passes by default
     idx = rng.integers(0, nc, big)
     idx[0] = nc                                                                           # first and last codeword of the launch
     idx[-1] = nc + 11

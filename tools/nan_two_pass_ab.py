@@ -26,11 +26,11 @@ def rate(fn, n):
 
 
 print("code    frames  nan_share   one_pass   two_pass    default   M codewords/s")
-for code, eb in ((LDPCCode.TM5120, 4.0),):
+for code, eb in ((LDPCCode.TM5120, 4.0), (LDPCCode.TM1280, 4.0)):
     data = rng.integers(0, 256, size=(256, code.k() // 8), dtype=np.uint8)
     cws = code.encode_batch(torch.from_numpy(data).to(dev))
     sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (eb / 10.0))))
-    for frames in (256, 512, 1024, 2048, 4096, 16384, 65536, 262144, 524288):
+    for frames in (256, 512, 1024, 2048, 4096, 16384, 65536, 262144, 524288) if code == LDPCCode.TM5120 else (4096, 16384, 65536, 262144, 1048576):
         for share in (0.0, 0.01) if frames >= 65536 else (0.0,):
             llrs = code.awgn_frames(cws, frames, sigma, seed=5, dtype="f32")
             if share:
