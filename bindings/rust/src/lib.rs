@@ -133,12 +133,15 @@ extern "C" {
     pub fn labrador_ldpc_llrs_to_hard_batch_f64(code: LDPCCode, llrs: *const f64, output: *mut u8, batch: usize, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_hip_awgn_f32(code: LDPCCode, codewords: *const u8, pool: usize, llrs: *mut f32, batch: usize, sigma: f32, seed: u64, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_hip_awgn_i8(code: LDPCCode, codewords: *const u8, pool: usize, llrs: *mut i8, batch: usize, sigma: f32, scale: f32, lim: c_int, seed: u64, opts: *const HipOpts) -> c_int;
+    pub fn labrador_ldpc_hip_awgn_f32_at(code: LDPCCode, codewords: *const u8, pool: usize, llrs: *mut f32, first_frame: u64, batch: usize, sigma: f32, seed: u64, opts: *const HipOpts) -> c_int;
+    pub fn labrador_ldpc_hip_awgn_i8_at(code: LDPCCode, codewords: *const u8, pool: usize, llrs: *mut i8, first_frame: u64, batch: usize, sigma: f32, scale: f32, lim: c_int, seed: u64, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_hip_edge_crc(code: LDPCCode) -> u32;
     pub fn labrador_ldpc_hip_edges(code: LDPCCode, checks: *mut u16, variables: *mut u16, cap: usize) -> usize;
     pub fn labrador_ldpc_hip_shard_range(batch: usize, parts: usize, index: usize, first: *mut usize, count: *mut usize) -> c_int;
     pub fn labrador_ldpc_hip_device_count() -> c_int;
     pub fn labrador_ldpc_hip_last_error() -> *const c_char;
     pub fn labrador_ldpc_hip_version() -> *const c_char;
+    pub fn labrador_ldpc_hip_build_id() -> *const c_char;
     pub fn labrador_ldpc_hip_abi_version() -> c_int;
 }
 

@@ -342,6 +342,17 @@ int labrador_ldpc_hip_awgn_f32(enum labrador_ldpc_code code, const uint8_t *code
 int labrador_ldpc_hip_awgn_i8 (enum labrador_ldpc_code code, const uint8_t *codewords, size_t pool,
                                int8_t *llrs, size_t batch, float sigma, float scale, int lim,
                                uint64_t seed, const struct labrador_ldpc_hip_opts *opts);
+/* The same for frames [first_frame, first_frame + batch) of a larger job: frame f of the call is global frame
+ * first_frame + f -- it takes codeword ((first_frame + f) mod pool) and the generator stream of that global index --
+ * so the shards of a job generated on N devices are, byte for byte, the slices of the buffer one call with
+ * first_frame = 0 writes (labrador_ldpc_hip_awgn_f32 / _i8 are these with first_frame = 0).  This is what makes an
+ * N-GPU run of the harness decode the very frames of the one-GPU run (perftest/src/main.rs:39-52: one job, N workers). */
+int labrador_ldpc_hip_awgn_f32_at(enum labrador_ldpc_code code, const uint8_t *codewords, size_t pool,
+                                  float *llrs, uint64_t first_frame, size_t batch, float sigma, uint64_t seed,
+                                  const struct labrador_ldpc_hip_opts *opts);
+int labrador_ldpc_hip_awgn_i8_at (enum labrador_ldpc_code code, const uint8_t *codewords, size_t pool,
+                                  int8_t *llrs, uint64_t first_frame, size_t batch, float sigma, float scale, int lim,
+                                  uint64_t seed, const struct labrador_ldpc_hip_opts *opts);
 
 /* Edge stream CRC of this library's own code tables, computed like the reference's
  * test_iter_parity (src/codes/mod.rs:508-533).  Lets a test pin the tables the kernels are
@@ -370,6 +381,12 @@ const char *labrador_ldpc_hip_last_error(void);
 
 /* Library version string. */
 const char *labrador_ldpc_hip_version(void);
+
+/* Identity of the loaded library's BUILD: 16 hex digits, a hash of what determines the code object -- the sources of
+ * labrador_ldpc_amd/csrc, this header, the compiler flags and the compiler's version (csrc/build_id.sh) -- not of the produced
+ * bytes, which hipcc does not reproduce bit for bit.  Two builds of one source tree report one id; any source or flag edit
+ * changes it.  Profiles record the id they were collected on (profiles/hbm_traffic.json, bench.py). */
+const char *labrador_ldpc_hip_build_id(void);
 
 /* The LABRADOR_LDPC_HIP_ABI the loaded library was built with: a client that dlopen()s the library compares it with its
  * own header's before passing a struct labrador_ldpc_hip_opts. */

@@ -85,12 +85,16 @@ SYMBOLS = {
     "labrador_ldpc_hip_awgn_f32": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_uint64, _optp]),
     "labrador_ldpc_hip_awgn_i8": (_int, [_int, _vp, _sz, _vp, _sz, _c.c_float, _c.c_float, _int,
                                          _c.c_uint64, _optp]),
+    "labrador_ldpc_hip_awgn_f32_at": (_int, [_int, _vp, _sz, _vp, _c.c_uint64, _sz, _c.c_float, _c.c_uint64, _optp]),
+    "labrador_ldpc_hip_awgn_i8_at": (_int, [_int, _vp, _sz, _vp, _c.c_uint64, _sz, _c.c_float, _c.c_float, _int,
+                                            _c.c_uint64, _optp]),
     "labrador_ldpc_hip_edge_crc": (_c.c_uint32, [_int]),
     "labrador_ldpc_hip_edges": (_sz, [_int, _vp, _vp, _sz]),
     "labrador_ldpc_hip_shard_range": (_int, [_sz, _sz, _sz, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "labrador_ldpc_hip_device_count": (_int, []),
     "labrador_ldpc_hip_last_error": (_c.c_char_p, []),
     "labrador_ldpc_hip_version": (_c.c_char_p, []),
+    "labrador_ldpc_hip_build_id": (_c.c_char_p, []),
     "labrador_ldpc_hip_abi_version": (_int, []),
 }
 
@@ -509,9 +513,11 @@ class LDPCCode(enum.IntEnum):
 
     # ---- synthetic channel (harness) ----
     def awgn_frames(self, codewords, batch: int, sigma: float, seed: int, dtype="f32",
-                    scale: float = 8.0, lim: int = 31, out=None, stream: Optional[int] = None):
+                    scale: float = 8.0, lim: int = 31, out=None, stream: Optional[int] = None, first_frame: int = 0):
         """Fill `out[batch, n]` (device tensor) with BPSK+AWGN LLRs of the device-resident
-        codeword pool `codewords[pool, n/8]` (see labrador_ldpc_hip_awgn_*)."""
+        codeword pool `codewords[pool, n/8]` (see labrador_ldpc_hip_awgn_*_at): frames
+        [first_frame, first_frame + batch) of the job `seed` names -- a shard generated with its own
+        first_frame equals that slice of the whole job's buffer byte for byte."""
         import torch
         if not (codewords.is_cuda and codewords.dtype == torch.uint8 and codewords.is_contiguous()):
             raise ValueError("codewords must be a contiguous uint8 CUDA tensor [pool, n/8]")
@@ -526,12 +532,12 @@ class LDPCCode(enum.IntEnum):
             stream = torch.cuda.current_stream(dev).cuda_stream
         opts = HipOpts(dev.index if dev.index is not None else -1, MEM_DEVICE, stream, 0, 0, None)
         if dtype == "f32":
-            _check(lib.labrador_ldpc_hip_awgn_f32(int(self), codewords.data_ptr(), codewords.shape[0],
-                                                  out.data_ptr(), batch, sigma, seed, ctypes.byref(opts)))
+            _check(lib.labrador_ldpc_hip_awgn_f32_at(int(self), codewords.data_ptr(), codewords.shape[0],
+                                                     out.data_ptr(), first_frame, batch, sigma, seed, ctypes.byref(opts)))
         else:
-            _check(lib.labrador_ldpc_hip_awgn_i8(int(self), codewords.data_ptr(), codewords.shape[0],
-                                                 out.data_ptr(), batch, sigma, scale, lim, seed,
-                                                 ctypes.byref(opts)))
+            _check(lib.labrador_ldpc_hip_awgn_i8_at(int(self), codewords.data_ptr(), codewords.shape[0],
+                                                    out.data_ptr(), first_frame, batch, sigma, scale, lim, seed,
+                                                    ctypes.byref(opts)))
         return out
 
 

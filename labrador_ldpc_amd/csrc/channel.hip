@@ -4,8 +4,11 @@
 // (/root/reference/perftest/src/main.rs:10-18: encode, hard_to_llrs -> +-1, add Normal noise)
 // done for a whole batch in HBM, so that the 16 GiB/GPU of LLRs of the TM8192 configuration
 // never cross PCIe.  One thread makes four consecutive samples: one Philox4x32-10 block
-// keyed by the seed and counted by (sample/4, frame), two Box-Muller pairs, one 16-byte
-// (f32) or 4-byte (i8) store -- fully coalesced, HBM-write bound.
+// keyed by the seed and counted by (sample/4, GLOBAL frame index), two Box-Muller pairs, one 16-byte
+// (f32) or 4-byte (i8) store -- fully coalesced, HBM-write bound.  The global frame index (first_frame +
+// the frame's position in the call) also picks the codeword from the pool, so a call that generates frames
+// [a, b) of a job writes exactly bytes [a, b) of the buffer a single call for the whole job would write:
+// the shards of an N-GPU run are slices of the one-GPU batch, bit for bit (labrador_ldpc_hip_awgn_*_at).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -59,14 +62,15 @@ template <> struct Quant<int8_t> {
 template <class T>
 __global__ void __launch_bounds__(256)
 awgn_kernel(const uint8_t *__restrict__ codewords, uint32_t pool, T *__restrict__ llrs,
-            uint32_t n, uint64_t total_quads, float sigma, float scale, int lim,
+            uint32_t n, uint64_t first_frame, uint64_t total_quads, float sigma, float scale, int lim,
             uint32_t seed_lo, uint32_t seed_hi)
 {
     const uint32_t quads_per_frame = n / 4;
     for (uint64_t qd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < total_quads;
          qd += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t frame = qd / quads_per_frame;
-        const uint32_t q = (uint32_t)(qd - frame * quads_per_frame);
+        const uint64_t local = qd / quads_per_frame;
+        const uint32_t q = (uint32_t)(qd - local * quads_per_frame);
+        const uint64_t frame = first_frame + local;
         const U4 rnd = philox4x32_10(U4{q, (uint32_t)frame, (uint32_t)(frame >> 32), 0u}, seed_lo, seed_hi);
         float z[4];
         box_muller(rnd.x, rnd.y, z[0], z[1]);
@@ -92,7 +96,7 @@ awgn_kernel(const uint8_t *__restrict__ codewords, uint32_t pool, T *__restrict_
 }  // namespace
 
 template <class T>
-hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, size_t batch, float sigma,
+hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, uint64_t first_frame, size_t batch, float sigma,
                        float scale, int lim, uint64_t seed, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
@@ -100,12 +104,12 @@ hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, si
     uint64_t blocks = (total_quads + 255) / 256;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
     hipLaunchKernelGGL((awgn_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, codewords,
-                       (uint32_t)pool, llrs, (uint32_t)n, total_quads, sigma, scale, lim,
+                       (uint32_t)pool, llrs, (uint32_t)n, first_frame, total_quads, sigma, scale, lim,
                        (uint32_t)seed, (uint32_t)(seed >> 32));
     return hipGetLastError();
 }
 
-template hipError_t launch_awgn<float>(const uint8_t *, size_t, float *, int, size_t, float, float, int, uint64_t, hipStream_t);
-template hipError_t launch_awgn<int8_t>(const uint8_t *, size_t, int8_t *, int, size_t, float, float, int, uint64_t, hipStream_t);
+template hipError_t launch_awgn<float>(const uint8_t *, size_t, float *, int, uint64_t, size_t, float, float, int, uint64_t, hipStream_t);
+template hipError_t launch_awgn<int8_t>(const uint8_t *, size_t, int8_t *, int, uint64_t, size_t, float, float, int, uint64_t, hipStream_t);
 
 }  // namespace ldpc

@@ -6,6 +6,6 @@
 
 namespace ldpc {
 template <class T>
-hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, size_t batch, float sigma,
+hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, uint64_t first_frame, size_t batch, float sigma,
                        float scale, int lim, uint64_t seed, hipStream_t stream);
 }

@@ -14,6 +14,18 @@ extern template hipError_t launch_one<TM5120, float, 1> LDPC_F32_SIG;
 extern template hipError_t launch_one<TM6144, float, 1> LDPC_F32_SIG;
 extern template hipError_t launch_one<TM6144, float, 2> LDPC_F32_SIG;
 
+// code -> default and alternative indices per thread (one table for the dispatch and for decode_ms_reads_llrs_once)
+#define LDPC_TABLE(X) \
+    X(TC128,  float, 1) \
+    X(TC256,  float, 1) \
+    X(TC512,  float, 1) \
+    X(TM1280, float, 1) \
+    X(TM1536, float, 1, 2) \
+    X(TM2048, float, 1, 2) \
+    X(TM5120, float, 1) \
+    X(TM6144, float, 1, 2) \
+    X(TM8192, float, 2, 4)
+
 template <>
 hipError_t launch_decode_ms<float>(int code, int variant, const float *llrs, uint8_t *output,
                                    uint32_t *iters, uint8_t *success, size_t batch,
@@ -29,16 +41,19 @@ hipError_t launch_decode_ms<float>(int code, int variant, const float *llrs, uin
         return hipErrorInvalidConfiguration;
     }
     switch (code) {
-        LDPC_CASE(TC128,  float, 1)
-        LDPC_CASE(TC256,  float, 1)
-        LDPC_CASE(TC512,  float, 1)
-        LDPC_CASE(TM1280, float, 1)
-        LDPC_CASE(TM1536, float, 1, 2)
-        LDPC_CASE(TM2048, float, 1, 2)
-        LDPC_CASE(TM5120, float, 1)
-        LDPC_CASE(TM6144, float, 1, 2)
-        LDPC_CASE(TM8192, float, 2, 4)
+        LDPC_TABLE(LDPC_CASE)
         default: return hipErrorInvalidValue;
+    }
+}
+
+template <>
+bool decode_ms_reads_llrs_once<float>(int code, int variant)
+{
+    if (variant != 0) return false;
+    if (code == TM8192) return true;             // the pair kernel holds its LLRs in registers
+    switch (code) {
+        LDPC_TABLE(LDPC_ONCE_CASE)
+        default: return false;
     }
 }
 

@@ -174,6 +174,19 @@ hipError_t launch_f64(const double *llrs, uint8_t *output, uint32_t *iters, uint
 hipError_t launch_decode_ms_f64_reg(int code, int ipt, int lean, const double *llrs, uint8_t *output, uint32_t *iters,
                                     uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
 
+// the tuned default per code, as a `variant` (re-measured on round 3's kernels, tools/f64_variants.py, M codewords/s: TM1280
+// plain 18.2 / lean 25.6 / in place 21.3; TM6144 in place 3.37 / lean 4.04 / lean with two indices 3.82; TM1536 plain 19.5 =
+// lean 19.4; the TC codes plain)
+static constexpr int F64_TUNED[NUM_CODES] = {1, 1, 1, 17, 1, 17, 17, 17, 34};
+
+// only the plain register kernel holds its f64 LLRs in registers (kernel_reads_llrs_once)
+template <>
+bool decode_ms_reads_llrs_once<double>(int code, int variant)
+{
+    if (variant != 0 || !valid_code(code)) return false;
+    return (F64_TUNED[code] & (16 | 32)) == 0;
+}
+
 // variant: 0 = tuned default; 100 = the workspace kernel above; otherwise the register kernel with
 // IPT = variant & 15, the register-lean check phase if variant & 16, in-place messages if variant & 32.
 template <>
@@ -183,12 +196,7 @@ hipError_t launch_decode_ms<double>(int code, int variant, const double *llrs, u
     if (batch == 0) return hipSuccess;
     if (!valid_code(code)) return hipErrorInvalidValue;
     if (variant >= 0) variant &= ~VARIANT_FLAGS;           // (the f64 kernels always draw from the launch's queue)
-    if (variant == 0) {
-        // (re-measured on round 3's kernels, tools/f64_variants.py, M codewords/s: TM1280 plain 18.2 / lean 25.6 / in place 21.3;
-        // TM6144 in place 3.37 / lean 4.04 / lean with two indices 3.82; TM1536 plain 19.5 = lean 19.4; the TC codes plain)
-        static constexpr int tuned[NUM_CODES] = {1, 1, 1, 17, 1, 17, 17, 17, 34};
-        variant = tuned[code];
-    }
+    if (variant == 0) variant = F64_TUNED[code];
     if (variant != 100)
         return launch_decode_ms_f64_reg(code, variant & 15, (variant & 32) ? 2 : ((variant & 16) ? 1 : 0), llrs, output, iters, success, batch,
                                         maxiters, stream);

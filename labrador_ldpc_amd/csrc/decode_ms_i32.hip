@@ -5,6 +5,18 @@
 
 namespace ldpc {
 
+// code -> default and alternative indices per thread (one table for the dispatch and for decode_ms_reads_llrs_once)
+#define LDPC_TABLE(X) \
+    X(TC128,  int32_t, 1) \
+    X(TC256,  int32_t, 1) \
+    X(TC512,  int32_t, 1) \
+    X(TM1280, int32_t, 1) \
+    X(TM1536, int32_t, 1) \
+    X(TM2048, int32_t, 1) \
+    X(TM5120, int32_t, 1) \
+    X(TM6144, int32_t, 1) \
+    X(TM8192, int32_t, 2)
+
 template <>
 hipError_t launch_decode_ms<int32_t>(int code, int variant, const int32_t *llrs, uint8_t *output,
                                      uint32_t *iters, uint8_t *success, size_t batch,
@@ -16,16 +28,19 @@ hipError_t launch_decode_ms<int32_t>(int code, int variant, const int32_t *llrs,
         return hipErrorInvalidConfiguration;
     }
     switch (code) {
-        LDPC_CASE(TC128,  int32_t, 1)
-        LDPC_CASE(TC256,  int32_t, 1)
-        LDPC_CASE(TC512,  int32_t, 1)
-        LDPC_CASE(TM1280, int32_t, 1)
-        LDPC_CASE(TM1536, int32_t, 1)
-        LDPC_CASE(TM2048, int32_t, 1)
-        LDPC_CASE(TM5120, int32_t, 1)
-        LDPC_CASE(TM6144, int32_t, 1)
-        LDPC_CASE(TM8192, int32_t, 2)
+        LDPC_TABLE(LDPC_CASE)
         default: return hipErrorInvalidValue;
+    }
+}
+
+template <>
+bool decode_ms_reads_llrs_once<int32_t>(int code, int variant)
+{
+    if (variant != 0) return false;
+    if (code == TM8192) return true;             // the pair kernel holds its LLRs in registers
+    switch (code) {
+        LDPC_TABLE(LDPC_ONCE_CASE)
+        default: return false;
     }
 }
 

@@ -25,6 +25,11 @@ template <class T>
 hipError_t launch_decode_ms(int code, int variant, const T *llrs, uint8_t *output, uint32_t *iters,
                             uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream);
 
+// Will launch_decode_ms<T>(code, variant, ...) read every LLR from memory exactly once?  (false for explicit variants, which
+// are not second-guessed, and for forced two-pass NaN handling, whose second kernel reads the first one's marks.)
+template <class T>
+bool decode_ms_reads_llrs_once(int code, int variant);
+
 // Largest |LLR| for which the f32 kernels may drop the FLT_MAX clamp of the exclusive minimum
 // (decoder.rs:414-415) for a run of `maxiters` iterations.  The clamp acts only if a magnitude overflows to
 // infinity.  With L = max |LLR|, V_k = max |v| and U_k = max |u| after iteration k:  U_k <= V_k (an exclusive
@@ -72,20 +77,43 @@ inline uint32_t *claim_counter(hipStream_t stream)
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     struct Block { uint32_t *base = nullptr; unsigned used = 0; };
     constexpr unsigned PER_BLOCK = 1024;
+    constexpr size_t MAX_HEADS = 8 * PER_BLOCK;      // streams beyond that (handle churn) run the fixed stride: the map stays bounded
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, uint32_t *> heads;
     static std::map<int, Block> blocks;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = heads.find({dev, stream});
-    if (it != heads.end()) return it->second;
-    Block &b = blocks[dev];
-    if (b.base == nullptr || b.used == PER_BLOCK) {
-        uint32_t *p = nullptr;
-        if (hipMalloc(&p, PER_BLOCK * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(p, 0, PER_BLOCK * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
-        b.base = p;
-        b.used = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = heads.find({dev, stream});
+        if (it != heads.end()) return it->second;
+        if (heads.size() >= MAX_HEADS) return nullptr;
+        Block &b = blocks[dev];
+        if (b.base != nullptr && b.used < PER_BLOCK) {
+            uint32_t *head = b.base + b.used++;
+            heads[{dev, stream}] = head;
+            return head;
+        }
     }
+    // A new block of queue heads for this device, allocated and zeroed OUTSIDE the lock (other workers' launches go on) and
+    // without a device-wide synchronisation: the zeroing runs on a private non-blocking stream and only that stream is waited
+    // for.  hipMalloc / hipStreamCreate are not capture-safe, so the thread's capture mode is relaxed around them: another
+    // thread's global-mode capture is not invalidated by this one's first use of a device (round 3 advice).
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    uint32_t *p = nullptr;
+    hipStream_t zs = nullptr;
+    bool ok = hipMalloc(&p, PER_BLOCK * sizeof(uint32_t)) == hipSuccess;
+    if (ok) ok = hipStreamCreateWithFlags(&zs, hipStreamNonBlocking) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(p, 0, PER_BLOCK * sizeof(uint32_t), zs) == hipSuccess && hipStreamSynchronize(zs) == hipSuccess;
+    if (zs) (void)hipStreamDestroy(zs);
+    if (!ok) { (void)hipGetLastError(); if (p) (void)hipFree(p); p = nullptr; }
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (p == nullptr) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = heads.find({dev, stream});             // (another thread may have served this stream meanwhile)
+    if (it != heads.end()) { (void)hipFree(p); return it->second; }
+    Block &b = blocks[dev];
+    if (b.base != nullptr && b.used < PER_BLOCK) (void)hipFree(p);      // ... or installed a fresh block: use that one
+    else { b.base = p; b.used = 0; }
     uint32_t *head = b.base + b.used++;
     heads[{dev, stream}] = head;
     return head;
@@ -210,23 +238,39 @@ hipError_t launch_cfg(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *
     }
 }
 
+// Which form of the one-index-per-thread kernel a (code, type) runs: 0 = plain, 1 = register-lean check phase.
+// Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
+// is TM5120 (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB) and the narrow types of TM1280.  Measured slower
+// on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
+// TM1280 i8 / i16: 168 -> 116 VGPRs, four waves per SIMD instead of three: 68.4 -> 71.0 (its f32 kernel 70.5 -> 69.5: not).
+// Re-measured on round 3's kernels (the lean check phase lost 70 VALU instructions per thread and iteration this round:
+// profiles/r03_kbench/kb27_lean_again.txt), lean against plain, M codewords/s: TM1280 f32 69.97 -> 74.48 (115 instead of 168
+// registers: 8 workgroups per CU instead of 6); TM2048 i8 51.47 -> 53.80 (64 instead of 80: 4 instead of 3); TM1536 i8
+// 65.84 -> 67.88 (5 instead of 4); still slower where it does not buy occupancy: TM1536 f32 69.3 -> 57.7, TM2048 f32 40.2 ->
+// 31.0, TM6144 f32 11.94 -> 9.68, i8 12.41 -> 11.79.
+template <int CODE, class T, int IPT>
+constexpr int lean_mode()
+{
+    constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
+    constexpr bool lean_code = CODE == TM5120 || (CODE == TM1280 && (narrow || std::is_same_v<T, float>)) || ((CODE == TM1536 || CODE == TM2048) && narrow);
+    return lean_code && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
+}
+
+// Does a kernel form read every LLR from memory exactly once?  The plain kernels and the pair kernel hold their LLRs in
+// registers; the register-lean kernel does so only for the narrow types (packed raw bytes), its f32 / f64 / i32 forms and the
+// in-place form (LEAN 2) re-read them in every variable phase.  capi.hip lets the smallest host calls read their input
+// across the link only when this holds (one predicate, next to the tables that pick the kernel: round 3 advice).
+template <class T, int LEAN>
+constexpr bool kernel_reads_llrs_once()
+{
+    return LEAN == 0 || (LEAN == 1 && (std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>));
+}
+
 template <int CODE, class T, int IPT>
 hipError_t launch_one(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
                       size_t batch, uint32_t maxiters, hipStream_t stream, unsigned lflags)
 {
-    // Register-lean variant (decode_ms_kernel.hpp): pays where it doubles the workgroups per CU, which
-    // is TM5120 (f32 12.4 -> 13.8, i8 11.3 -> 13.8 M codewords/s at 4 dB) and the narrow types of TM1280.  Measured slower
-    // on TM1280 / TM1536 / TM2048 / TM6144 f32 (-7..-8 %), whose occupancy it does not change.
-    // TM1280 i8 / i16: 168 -> 116 VGPRs, four waves per SIMD instead of three: 68.4 -> 71.0 (its f32 kernel 70.5 -> 69.5: not).
-    // Re-measured on round 3's kernels (the lean check phase lost 70 VALU instructions per thread and iteration this round:
-    // profiles/r03_kbench/kb27_lean_again.txt), lean against plain, M codewords/s: TM1280 f32 69.97 -> 74.48 (115 instead of 168
-    // registers: 8 workgroups per CU instead of 6); TM2048 i8 51.47 -> 53.80 (64 instead of 80: 4 instead of 3); TM1536 i8
-    // 65.84 -> 67.88 (5 instead of 4); still slower where it does not buy occupancy: TM1536 f32 69.3 -> 57.7, TM2048 f32 40.2 ->
-    // 31.0, TM6144 f32 11.94 -> 9.68, i8 12.41 -> 11.79.
-    constexpr bool narrow = std::is_same_v<T, int8_t> || std::is_same_v<T, int16_t>;
-    constexpr bool lean_code = CODE == TM5120 || (CODE == TM1280 && (narrow || std::is_same_v<T, float>)) || ((CODE == TM1536 || CODE == TM2048) && narrow);
-    constexpr int LEAN = lean_code && IPT == 1 && !std::is_same_v<T, int32_t> ? 1 : 0;   // (i32's wider integer sequences spill at the lean kernel's 128-VGPR budget)
-    return launch_cfg<CODE, T, IPT, LEAN>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+    return launch_cfg<CODE, T, IPT, lean_mode<CODE, T, IPT>()>(llrs, output, iters, success, batch, maxiters, stream, lflags);
 }
 
 // Pair-ownership kernel (decode_ms_pair.hpp): one workgroup per CU-resident codeword, persistent.
@@ -283,6 +327,9 @@ hipError_t launch_pair(const T *llrs, uint8_t *output, uint32_t *iters, uint8_t 
                                                          output, iters, success, batch, maxiters, \
                                                          stream, lflags);                        \
     }
+// the same table row as a `case` of decode_ms_reads_llrs_once<T>(): the DEFAULT kernel of the code
+#define LDPC_ONCE_CASE(CODE, T, DEF, ...)                                                        \
+    case CODE: return kernel_reads_llrs_once<T, lean_mode<CODE, T, DEF>()>();
 #define LDPC_SPLIT_VARIANT()                                                                     \
     unsigned lflags = 0;                                                                         \
     if (variant >= 0) {                                                                          \

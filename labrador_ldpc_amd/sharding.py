@@ -27,7 +27,9 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def frame_seed(base_seed: int, rank: int) -> int:
-    """Per-rank 64-bit seed: frames of different ranks use disjoint generator streams."""
+    """Per-rank 64-bit seed: frames of different ranks use disjoint generator streams.  (bench.py no longer uses it: since
+    round 4 frames are keyed by their GLOBAL index in the job -- labrador_ldpc_hip_awgn_*_at -- so that a shard is a slice of
+    the one-GPU batch bit for bit; the per-rank seed remains for harnesses that want independent streams per worker.)"""
     return (base_seed & 0xFFFFFFFFFF) | ((rank & 0xFFFFFF) << 40)
 
 
@@ -125,3 +127,15 @@ def reduce_sum(values: Sequence[float], device=None) -> Sequence[float]:
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
+
+
+def reduce_sum_int(values: Sequence[int]) -> Sequence[int]:
+    """Element-wise EXACT integer SUM over ranks (int64; the float64 of reduce_sum is exact only to 2^53): iteration totals,
+    failure counts and the job digest of bench.py, which must be equal whatever the number of ranks."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]

@@ -143,3 +143,68 @@ def test_config4_whole_batch_on_one_gpu():
     clean = _hard_llrs(code, out[sub], "f32")
     o3, i3, k3 = code.decode_ms_batch(clean, maxiters)
     assert bool((k3 == 1).all()) and bool((i3 <= 1).all()) and torch.equal(o3, out[sub])
+
+
+@pytest.mark.parametrize("ebn0", [4.0, 2.0], ids=["4dB", "2dB-fixed-work"])
+def test_config5_whole_batch_on_one_gpu(ebn0):
+    """BASELINE configs[4] at its OWN batch: all 4 194 304 TM5120 i8 frames (20 GiB of LLRs) in one device-resident batch -- the
+    `config5_TM5120_i8_whole_*` entries of bench.py (round 3's review, missing #2).  Queue-fed and fixed-stride distribution give
+    identical results; the first and the last 524 288-frame slice (GPUs 0 and 7 of an 8-GPU run) decoded alone equal their part
+    of the whole; a shard GENERATED alone by global frame index is that slice of the buffer; oracle samples at the start, the
+    middle and the end."""
+    code, frames, maxiters = LDPCCode.TM5120, 4194304, 25
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40 * 2 ** 30:
+        pytest.skip(f"needs ~30 GB of free HBM, {free / 2 ** 30:.0f} GB available")
+    sigma = float(np.sqrt(1.0 / (2.0 * 0.8 * 10.0 ** (ebn0 / 10.0))))
+    d_pool = torch.from_numpy(_pool(code, 64, 0x1DBC + int(code))).to(dev)
+    llrs = code.awgn_frames(d_pool, frames, sigma, seed=0x1DBC + int(code), dtype="i8")
+    out, iters, ok = code.decode_ms_batch(llrs, maxiters)
+    torch.cuda.synchronize()
+    okb = ok.bool()
+    assert bool((iters[okb] < maxiters).all()) and bool((iters[~okb] == maxiters).all())
+    if ebn0 <= 2.0:
+        assert not bool(okb.any())                                          # a rate-4/5 code at 2 dB: nothing converges
+    else:
+        assert 0.9 < float(okb.float().mean()) <= 1.0
+
+    out2 = torch.empty_like(out)
+    it2, ok2 = torch.empty_like(iters), torch.empty_like(ok)
+    code.decode_ms_batch(llrs, maxiters, output=out2, iters=it2, success=ok2, variant=256)          # fixed stride
+    assert torch.equal(out, out2) and torch.equal(iters, it2) and torch.equal(ok, ok2)
+    del out2
+
+    S = 524288
+    for lo in (0, frames - S):
+        o_s, i_s, k_s = code.decode_ms_batch(llrs[lo:lo + S], maxiters)
+        assert torch.equal(o_s, out[lo:lo + S]) and torch.equal(i_s, iters[lo:lo + S]) and torch.equal(k_s, ok[lo:lo + S])
+        del o_s
+    # the last GPU's shard generated on its own (global frame index): the very bytes of the one-GPU buffer
+    shard = code.awgn_frames(d_pool, S, sigma, seed=0x1DBC + int(code), dtype="i8", first_frame=frames - S)
+    assert torch.equal(shard, llrs[frames - S:])
+    del shard
+
+    for lo in (0, frames // 2 - 128, frames - 256):
+        h = llrs[lo:lo + 256].cpu().numpy()
+        o_c, i_c, k_c, _ = oracle.decode_ms_batch(code, h, maxiters)
+        assert (out[lo:lo + 256].cpu().numpy() == o_c).all()
+        assert (iters[lo:lo + 256].cpu().numpy().astype(np.int64) == i_c.astype(np.int64)).all()
+        assert (ok[lo:lo + 256].cpu().numpy() == k_c).all()
+
+
+@pytest.mark.parametrize("code,dtype", [(LDPCCode.TM8192, "f32"), (LDPCCode.TM5120, "i8"), (LDPCCode.TC128, "f32")])
+def test_frames_are_keyed_by_global_frame_index(code, dtype):
+    """labrador_ldpc_hip_awgn_*_at: any contiguous shard of a job, generated alone with its first_frame, is byte for byte that
+    slice of the buffer one call generates -- including the codeword each frame carries (global index mod pool)."""
+    dev = torch.device("cuda", 0)
+    d_pool = torch.from_numpy(_pool(code, 7, 99)).to(dev)
+    total = 1000
+    whole = code.awgn_frames(d_pool, total, 0.7, seed=4242, dtype=dtype)
+    for lo, hi in ((0, 1), (1, 334), (334, 1000), (999, 1000), (500, 500)):
+        part = code.awgn_frames(d_pool, hi - lo, 0.7, seed=4242, dtype=dtype, first_frame=lo)
+        assert torch.equal(part, whole[lo:hi]), (lo, hi)
+    other = code.awgn_frames(d_pool, 10, 0.7, seed=4243, dtype=dtype)
+    assert not torch.equal(other, whole[:10])
+    far = code.awgn_frames(d_pool, 4, 0.7, seed=4242, dtype=dtype, first_frame=2 ** 33 + 5)       # beyond 32 bits of frame index
+    assert not torch.equal(far, whole[5:9]) and bool(torch.isfinite(far.float()).all())

@@ -54,3 +54,20 @@ def test_ranks_that_each_see_one_visible_device():
                         "--rank-parity-frames", "32", "--no-configs"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     _check(_one_json_line(r.stdout), 2, 16384)
+
+
+def test_an_n_gpu_job_is_the_one_gpu_job_bit_for_bit():
+    """Round 3's review, weak #7 (i): rank r used to generate its shard from its own seed, so an 8-GPU run decoded different bits
+    from the one-GPU batch.  Frames are now keyed by their global index, so the job's exact integer results -- sum of the
+    iteration counts, failed frames, and the position-weighted digest of every hard decision -- must be EQUAL for 1, 2, 3 and 8
+    ranks (all on device 0 here; on the driver's node the same three numbers tie SCALE N=8 to BENCH N=1)."""
+    total, seen = 40961, {}
+    for world in (1, 2, 3, 8):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--devices", ",".join(["0"] * world), "--total-frames", str(total),
+                            "--steps", "1", "--warmup", "0", "--no-cpu", "--no-configs"], capture_output=True, text=True, cwd=ROOT, timeout=1500)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        d = _one_json_line(r.stdout)
+        assert d["n_gpus"] == world and d["config"]["total_frames"] == total
+        seen[world] = (d["diag"]["job_digest"], d["diag"]["iters_sum"], d["diag"]["failed_frames"], d["diag"]["mean_iters_returned"])
+    assert len(set(seen.values())) == 1, seen
+    assert seen[1][1] > total * 5 and 0 <= seen[1][2] < total // 10

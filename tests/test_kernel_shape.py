@@ -11,17 +11,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "build", "csrc", "decode_ms_f32.o")) or
-                    not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs the built objects and llvm-objdump")
-def test_decode_kernels_have_uniform_control_flow():
+@pytest.fixture(scope="module")
+def built_objects():
+    """The guards below read build/csrc/*.o, which is git-ignored: on a fresh checkout they used to skip silently (round 3's
+    review, weak #10).  The objects are built here instead (`make` is a no-op when they are current; ~2 minutes from scratch)."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.fail("hipcc / llvm-objdump missing: the kernel-shape guards cannot run in this environment")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "labrador_ldpc_amd", "csrc"), "-j", str(min(8, os.cpu_count() or 1))],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(os.path.join(ROOT, "build", "csrc", "decode_ms_f32.o"))
+
+
+def test_decode_kernels_have_uniform_control_flow(built_objects):
     import scan_kernels
     table = scan_kernels.scan()
     assert len(table) >= 60
-    # (round 3: the queue draw -- one lane's atomic, its collection, the reset -- adds four small EXEC-guarded regions per
-    # quarter-specialised body, and the compiler also writes some wave-uniform jumps as s_cbranch_execnz: the in-place f64
-    # kernels reach 21-25, the mis-structured kernels of round 2 had 119 and more)
+    # EXEC-guarded regions per kernel.  The queue draw -- one lane's atomic, its collection, the reset -- adds about four small
+    # ones per quarter-specialised body, and the compiler writes some wave-uniform jumps as s_cbranch_execnz: the f32 / integer
+    # kernels measure 0-13 (bound 16 + nothing: the bound of round 2 still holds with the queue), the in-place f64
+    # instantiations (LEAN 2) 25-29 (their own bound, 40); the mis-structured kernels of round 2 had 119 and more.
+    def bound(name):
+        f64_register_kernel = "decode_ms_kernelILi" in name and "EdLi" in name       # decode_ms_kernel<CODE, double, ...>
+        return 40 if f64_register_kernel else 16
     bad = {k: v for k, v in table.items()
-           if v[1] > 40 and "decode_ms_f64_kernel" not in k[1]}     # the f64 workspace fallback (variant 100) is a plain loop kernel
+           if v[1] > bound(k[1]) and "decode_ms_f64_kernel" not in k[1]}     # the f64 workspace fallback (variant 100) is a plain loop kernel
     assert not bad, f"kernels with EXEC-masked loops (mis-structured control flow): {bad}"
 
 
@@ -45,9 +60,7 @@ def test_library_build_refuses_tuning_and_diagnostic_switches(tmp_path):
     assert ok.returncode == 0, ok.stderr[-300:]
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "build", "csrc", "decode_ms_f32.o")) or
-                    not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs the built objects and llvm-objdump")
-def test_no_spill_traffic_inside_the_iteration_loops():
+def test_no_spill_traffic_inside_the_iteration_loops(built_objects):
     """Spilled registers are tolerable in a kernel's prologue and epilogue, not in its iteration loop (the in-wave
     verdict at a 128-register budget put 6 scratch loads per iteration into TC512's loop: 273 -> 180 M codewords/s,
     results unchanged).  Every f32 / i8 / i16 / i32 kernel's loops -- backward branches spanning two workgroup

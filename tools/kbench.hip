@@ -57,7 +57,7 @@ int main()
     uint8_t *pool; KT *llrs; uint8_t *out, *ok; uint32_t *iters;
     CK(hipMalloc(&pool, n / 8)); CK(hipMemset(pool, 0, n / 8));
     CK(hipMalloc(&llrs, FMAX * n * sizeof(KT))); CK(hipMalloc(&out, FMAX * ol)); CK(hipMalloc(&ok, FMAX)); CK(hipMalloc(&iters, FMAX * 4));
-    CK(launch_awgn<KT>(pool, 1, llrs, (int)n, FMAX, sigma, 8.f, 31, 0x1DBCull + code, nullptr));
+    CK(launch_awgn<KT>(pool, 1, llrs, (int)n, 0, FMAX, sigma, 8.f, 31, 0x1DBCull + code, nullptr));
     using GEO = Geometry<code, KT, KIPT>;
     unsigned groups = (unsigned)((F + GEO::G - 1) / GEO::G);
     {   // the launcher's grid (decode_ms_launch.hpp): the resident set with the queue, 16x it (where several workgroups share a CU) without

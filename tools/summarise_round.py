@@ -19,10 +19,14 @@ for f in newest(f"{src}/trace/*/*_kernel_stats.csv"):
 for f in ("bench_default.json", "trace_bench.log"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{'bench_under_rocprof.log' if f == 'trace_bench.log' else f}")
-CONFIGS = {"TM8192_f32": (65536, 8192 * 4 + 1280 + 5), "TC512_f32": (65536, 512 * 4 + 64 + 5),
-           "TM2048_f32": (262144, 2048 * 4 + 320 + 5), "TM5120_i8": (131072, 5120 + 704 + 5)}
+# tag of tools/prof_round.sh -> (frames per launch, algorithmic bytes per frame, Eb/N0, max_iters): a profile entry belongs to ONE
+# operating point (bench.py profile_key: "<code>_<dtype>_<Eb/N0>dB_<max_iters>it")
+CONFIGS = {"TM8192_f32": (65536, 8192 * 4 + 1280 + 5, 2.0, 25), "TC512_f32": (65536, 512 * 4 + 64 + 5, 2.0, 25),
+           "TM2048_f32": (262144, 2048 * 4 + 320 + 5, 2.0, 25), "TM5120_i8": (131072, 5120 + 704 + 5, 4.0, 25),
+           "TM5120_i8_2dB": (131072, 5120 + 704 + 5, 2.0, 25)}
 traffic, allsum = {}, {}
-for tag, (frames, alg) in CONFIGS.items():
+for tag, (frames, alg, ebn0, maxit) in CONFIGS.items():
+    key = f"{'_'.join(tag.split('_')[:2])}_{ebn0:g}dB_{maxit}it"
     summary = {}
     for i in range(1, 6):
         for f in newest(f"{src}/{tag}.pmc{i}/*/*_counter_collection.csv"):
@@ -38,10 +42,10 @@ for tag, (frames, alg) in CONFIGS.items():
                 summary[cname] = sum(per.values()) / len(per)          # mean per launch
     if not summary:
         continue
-    allsum[tag] = dict(summary, frames_per_launch=frames)
+    allsum[tag] = dict(summary, frames_per_launch=frames, profile_key=key)
     if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
         hbm = (2.0 * summary["FETCH_SIZE"] + summary["WRITE_SIZE"]) * 1024.0      # KB -> B; FETCH_SIZE doubled: gfx950 correction
-        traffic[tag] = {"frames": frames, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": frames * alg,
+        traffic[key] = {"frames": frames, "ebn0_db": ebn0, "max_iters": maxit, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": frames * alg,
                         "hbm_over_algorithmic": hbm / (frames * alg),
                         "fetch_size_kb_raw": summary["FETCH_SIZE"], "write_size_kb_raw": summary["WRITE_SIZE"],
                         "valu_insts_per_launch": summary.get("SQ_INSTS_VALU"), "lds_insts_per_launch": summary.get("SQ_INSTS_LDS"),
@@ -49,8 +53,8 @@ for tag, (frames, alg) in CONFIGS.items():
                                 "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md"}
 json.dump(allsum, open(f"{dst}/pmc_summary.json", "w"), indent=1)
 mix = f"{dst}/valu_mix_tm8192_f32.json"              # tools/valu_mix.py (static instruction mix of the iteration loop)
-if os.path.exists(mix) and "TM8192_f32" in traffic:
-    traffic["TM8192_f32"]["avg_issue_cycles_per_instruction"] = json.load(open(mix))["avg_issue_cycles_per_instruction"]
+if os.path.exists(mix) and "TM8192_f32_2dB_25it" in traffic:
+    traffic["TM8192_f32_2dB_25it"]["avg_issue_cycles_per_instruction"] = json.load(open(mix))["avg_issue_cycles_per_instruction"]
 # the library build the counters were collected on (the bench line of the same gpurun call names it): bench.py reports
 # `traffic` / `valu_issue` only when the library it loaded is this one (tests/test_bench_host.py)
 build = None
@@ -69,4 +73,4 @@ for tag, s in allsum.items():
     if w:
         print(tag, {k: round(s[k] / w, 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS") if k in s},
               "LDS conflict share", round(s.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, s.get("SQ_LDS_IDX_ACTIVE", 1)), 3),
-              "HBM/alg", round(traffic[tag]["hbm_over_algorithmic"], 4) if tag in traffic else None)
+              "HBM/alg", round(traffic[s["profile_key"]]["hbm_over_algorithmic"], 4) if s["profile_key"] in traffic else None)
