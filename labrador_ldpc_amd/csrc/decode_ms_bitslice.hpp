@@ -1,0 +1,369 @@
+// decode_ms_bitslice.hpp -- BIT-SLICED min-sum decoder for i8 LLRs on the CCSDS TM (AR4JA) codes.
+//
+// The same algorithm as decode_ms_kernel.hpp -- LDPCCode::decode_ms::<i8>, /root/reference/src/decoder.rs:347-475 with the
+// i8 arithmetic of :42-50 -- in a different machine representation.  The f32-pipe kernels hold an i8 message in a 32-bit
+// register (round 3's review: "the narrow types save only LLR bytes"); SDWA byte selects were measured at HALF rate on
+// gfx950 (profiles/r04_kbench/sdwa_rate.txt), so packing bytes buys nothing.  Here a message costs what it carries, ONE
+// BIT PER BIT: a 32-bit register holds ONE BIT PLANE of 32 different indices of a block, an i8 value is 8 registers, and
+// every arithmetic step is a Boolean function on planes -- v_bitop3_b32 (any 3-input function, full rate) is the only
+// arithmetic instruction of the iteration loop.  One wave instruction processes 64 lanes x 32 bits = 2048 edges.
+//
+//  * LAYOUT.  The TM codes' blocks are the identity or a CCSDS permutation pi_k, which moves quarter q of a block to quarter
+//    (theta_k + q) mod 4 and rotates it by phi_k(q) (/root/reference/src/codes/mod.rs:313-317).  Index i = q * M/4 + j of a
+//    block lives in lane (q, j mod L), bit j / L, with L = M/128 lanes per quarter.  A rotation of the quarter by phi is then
+//    a lane permutation (phi mod L) plus ONE rotation of the 32-bit word (by phi / L, +1 where the lane index wraps):
+//    ds_bpermute_b32 + v_alignbit_b32 per plane, no funnel of two words.  M/32 lanes hold a codeword (TM8192: the whole
+//    wave; TM2048: 16 lanes, four codewords per wave, iterating in lockstep until the last one is done).
+//
+//  * STATE, compressed as hardware decoders keep it -- what DESIGN.md 7(a) costed as a loss for the f32 pipe is the natural
+//    form here.  Per check row (per index bit): min1, min2 (7 planes each), the product of the signs, and the slot of the
+//    edge that holds min1 (the reference's "|v| == min1 ? min2 : min1", decoder.rs:391-395, selects by VALUE; selecting by
+//    that slot gives the same u: if two edges tie at min1 then min2 == min1).  Per edge: sign(v) and v != 0 -- all the
+//    self-correction reads of the old v (decoder.rs:422).  TM8192: 90 planes = 90 VGPRs per lane hold the whole codeword.
+//
+//  * ORDER.  Block column by block column: marginal = LLR (+sat) u ... in the reference's edge order restricted to the
+//    variable (decoder.rs:408), then at once the check side of the same edges: nv = va (-sat) u, self-correction, sign and
+//    parity products, and the insertion of |v| into the row's two running minima (strict `<`, decoder.rs:430-434; as values
+//    the two smallest of a multiset do not depend on the order).  The old row state is read-only during an iteration, the
+//    new one replaces it at the end.  No barriers: a codeword never leaves its wave.
+//
+//  * |v| WITHOUT AN INCREMENT.  saturating_abs (decoder.rs:46) is v ^ sign + sign; the comparisons run on the key
+//    2 * (v ^ sign) + sign instead, which orders like |v| with ties split by sign, and only the two minima of a row are
+//    converted back, (key + 1) >> 1.  -128 takes the key of +127 (decoder.rs:46: |-128| = 127).
+//
+// The code below is written against a small backend `B` (one wave's registers as values of type B::V): HipBackend compiles it
+// for gfx950, tests/bitslice_emu.cpp runs the same text lane by lane on the CPU, where it is compared with the oracle.
+#pragma once
+
+#include <cstdint>
+
+#include "codes.hpp"
+
+#ifndef BS_FN
+#if defined(__HIPCC__)
+#define BS_FN __device__ __forceinline__
+#else
+#define BS_FN inline
+#endif
+#endif
+
+namespace ldpc {
+namespace bs {
+
+template <int N> struct IC { static constexpr int value = N; };
+template <int B0, int E, class F>
+BS_FN void sfor(F &&f)
+{
+    if constexpr (B0 < E) { f(IC<B0>{}); sfor<B0 + 1, E>(f); }
+}
+
+// truth tables of v_bitop3_b32: bit (a << 2 | b << 1 | c) of the constant is f(a, b, c)
+enum : int { TT_XOR3 = 0x96, TT_MAJ = 0xE8, TT_MUX = 0xCA /* a ? b : c */, TT_OR3 = 0xFE, TT_AND3 = 0x80,
+             TT_A_AND_NOT_B_XOR_C = 0x48 /* unused */ };
+
+constexpr int ilog2c(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+// ---- geometry of a code in the bit-sliced layout ----------------------------------------------------------------------
+template <int CODE>
+struct Geo {
+    static constexpr Prototype P = *CODES[CODE].proto;
+    static constexpr int M = CODES[CODE].m, N = CODES[CODE].n, NP = N + CODES[CODE].p;
+    static constexpr int Q = M / 4;                 // indices per quarter
+    static constexpr int L = Q / 32;                // lanes per quarter
+    static constexpr int W = 4 * L;                 // lanes per codeword
+    static constexpr int G = 64 / W;                // codewords per wave
+    static constexpr int NB = P.n_blocks, NROWS = P.n_rows, NCOLS = P.n_cols, NTX = N / M;
+    static constexpr int OUT_LEN = NP / 8;
+    static_assert(M >= 128 && (M & (M - 1)) == 0 && L >= 1 && W <= 64, "TM codes only");
+    static constexpr int row_degree(int r) { int c = 0; for (int b = 0; b < NB; ++b) c += P.blk[b].row == r; return c; }
+    static constexpr int max_row_degree() { int m = 0; for (int r = 0; r < NROWS; ++r) m = row_degree(r) > m ? row_degree(r) : m; return m; }
+    static constexpr int ARG = ilog2c(max_row_degree());          // planes of the arg-min slot
+    // slot of block b inside its row (the arg-min identifier)
+    static constexpr int slot_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += P.blk[i].row == P.blk[b].row; return s; }
+    static constexpr bool local(int b) { return P.blk[b].kind == BLK_I && P.blk[b].val == 0; }
+    // LDS words: LLR planes [NTX][8][64], a 2048-byte staging slab, hard-decision words [NCOLS][64]
+    static constexpr int LDS_LLR = 0, LDS_STAGE = NTX * 8 * 64 * 4, LDS_HARD = LDS_STAGE + 2048, LDS_BYTES = LDS_HARD + NCOLS * 64 * 4;
+};
+
+// ---- arithmetic on bit planes -------------------------------------------------------------------------------------------
+template <class B>
+struct Arith {
+    using V = typename B::V;
+    template <int TT> static BS_FN V op3(V a, V b, V c) { return B::template bitop3<TT>(a, b, c); }
+
+    // acc (+sat) / (-sat) u for two's-complement acc[8] and sign-magnitude u = (su, mg[7]), i8 saturation (decoder.rs:47-48).
+    // `negate` subtracts: the sign of u is flipped (u is never -128: |u| <= 127).
+    template <bool NEGATE>
+    static BS_FN void sat_addsub(V (&acc)[8], V su, const V (&mg)[7])
+    {
+        const V s = NEGATE ? B::not_(su) : su;                // sign of the addend
+        V x[7], sum[8];
+        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], s); });     // one's complement if negative ...
+        V c = s;                                              // ... + 1 through the carry-in
+        sfor<0, 7>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            sum[k] = op3<TT_XOR3>(acc[k], x[k], c);
+            c = op3<TT_MAJ>(acc[k], x[k], c);
+        });
+        sum[7] = op3<TT_XOR3>(acc[7], s, c);                  // the addend's bit 7 is its sign (sign extension)
+        // overflow iff both operands have the same sign and the sum's differs:  (a7 == s) & (sum7 != a7)
+        // as a function of (a7, s, sum7): 001 -> a7=0,s=0,sum7=1: yes; 110 -> a7=1,s=1,sum7=0: yes  => 0x42
+        const V ovf = op3<0x42>(acc[7], s, sum[7]);
+        // saturated value: 0x7F if acc >= 0 (a7 = 0), 0x80 if acc < 0: planes 0..6 = ~a7, plane 7 = a7
+        const V a7 = acc[7];
+        sfor<0, 7>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            acc[k] = op3<0x4E>(ovf, a7, sum[k]);              // ovf ? ~a7 : sum   (a=ovf, b=a7, c=sum): 0x4E
+        });
+        acc[7] = op3<TT_MUX>(ovf, a7, sum[7]);
+    }
+
+    // a < b for 8-plane unsigned keys: the borrow out of a - b
+    static BS_FN V less_than(const V (&a)[8], const V (&b)[8])
+    {
+        V br = B::andn(b[0], a[0]);                           // ~a0 & b0
+        sfor<1, 8>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            br = op3<0x8E>(b[k], a[k], br);                   // borrow' = maj(~a, b, borrow)  as f(b, a, br): 0x8E
+        });
+        return br;
+    }
+};
+
+// truth-table self-check helpers (compile time): f(a,b,c) listed for index a<<2|b<<1|c
+constexpr int tt_of(bool (*f)(bool, bool, bool))
+{
+    int t = 0;
+    for (int i = 0; i < 8; ++i) t |= (f((i >> 2) & 1, (i >> 1) & 1, i & 1) ? 1 : 0) << i;
+    return t;
+}
+static_assert(tt_of([](bool a, bool b, bool c) { return a ? b : c; }) == TT_MUX);
+static_assert(tt_of([](bool a, bool b, bool c) { return (a ^ b ^ c); }) == TT_XOR3);
+static_assert(tt_of([](bool a, bool b, bool c) { return (a && b) || (c && (a || b)); }) == TT_MAJ);
+static_assert(tt_of([](bool a7, bool s, bool sum7) { return (a7 == s) && (sum7 != a7); }) == 0x42);
+static_assert(tt_of([](bool ovf, bool a7, bool sum) { return ovf ? !a7 : sum; }) == 0x4E);
+static_assert(tt_of([](bool b, bool a, bool br) { return (!a && b) || (br && (!a || b)); }) == 0x8E);
+
+// ---- the decoder of one group of G codewords, executed by one wave --------------------------------------------------------
+template <int CODE, class B>
+struct Decoder {
+    using V = typename B::V;
+    using GEO = Geo<CODE>;
+    using A = Arith<B>;
+    static constexpr int M = GEO::M, L = GEO::L, W = GEO::W, G = GEO::G, NB = GEO::NB, NROWS = GEO::NROWS, NCOLS = GEO::NCOLS, NTX = GEO::NTX;
+    static constexpr int ARG = GEO::ARG;
+    template <int TT> static BS_FN V op3(V a, V b, V c) { return B::template bitop3<TT>(a, b, c); }
+
+    // lane constants
+    V lane, q, ll, cwbase;
+    // old row state (read-only during an iteration) and per-edge bits
+    V m1[NROWS][7], m2[NROWS][7], S[NROWS], arg[NROWS][ARG];
+    V sv[NB], nz[NB];
+    // new row state of the running iteration: keys (8 planes), sign product, parity, arg-min slot
+    V W1[NROWS][8], W2[NROWS][8], Sn[NROWS], Pn[NROWS], argn[NROWS][ARG];
+    V hard[NCOLS];
+
+    BS_FN void init_lane(B &b)
+    {
+        lane = b.lane();
+        ll = B::and_(lane, B::c(L - 1));
+        q = B::and_(B::shr(lane, ilog2c(L)), B::c(3));
+        cwbase = B::and_(lane, B::c(~(W - 1) & 63));
+    }
+
+    BS_FN void reset_state()
+    {
+        // decoder.rs:374: the working area is zeroed, so before iteration 0 min1 = min2 = 0, every v = 0, every sign product +
+        sfor<0, NROWS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
+            S[r] = B::c(0);
+            sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
+        });
+        sfor<0, NB>([&](auto E_) { constexpr int e = decltype(E_)::value; sv[e] = B::c(0); nz[e] = B::c(0); });
+        sfor<0, NCOLS>([&](auto C_) { hard[decltype(C_)::value] = B::c(0); });
+    }
+
+    // "this edge holds the row's min1": arg[r] == slot
+    template <int R, int SLOT>
+    BS_FN V is_arg() const
+    {
+        // AND over the ARG planes of (plane == bit of SLOT); planes taken three at a time
+        V acc = B::c(0xFFFFFFFFu);
+        auto lit = [&](int k) { return ((SLOT >> k) & 1) ? arg[R][k] : B::not_(arg[R][k]); };
+        if constexpr (ARG == 0) return acc;
+        else {
+            // fold with truth tables that absorb the complements: f = acc & (x0 ^ ~s0) & (x1 ^ ~s1)
+            constexpr int s0 = SLOT & 1, s1 = (SLOT >> 1) & 1;
+            if constexpr (ARG == 1) return lit(0);
+            else {
+                // first pair
+                constexpr int tt2 = (s0 && s1) ? 0x88 : (s0 && !s1) ? 0x22 : (!s0 && s1) ? 0x44 : 0x11;     // f(a=x1? ..) see below
+                // op3 inputs (a, b, c) = (unused acc = all ones, x1, x0): value must be (x0 == s0) & (x1 == s1); index bit1 = x1, bit0 = x0
+                // with a = 1 the relevant entries are 4..7, with a = 0 entries 0..3; fill both halves identically
+                V r2 = op3<tt2>(acc, arg[R][1], arg[R][0]);
+                if constexpr (ARG == 2) return r2;
+                else {
+                    V r = r2;
+                    sfor<2, ARG>([&](auto K_) {
+                        constexpr int k = decltype(K_)::value;
+                        r = ((SLOT >> k) & 1) ? B::and_(r, arg[R][k]) : B::andn(r, arg[R][k]);          // r & x  /  r & ~x
+                    });
+                    return r;
+                }
+            }
+        }
+    }
+
+    // u of edge E at CHECK alignment: sign su, magnitude mg[7]  (decoder.rs:391-405 from the compressed row state)
+    template <int E>
+    BS_FN void edge_u(V &su, V (&mg)[7]) const
+    {
+        constexpr int r = GEO::P.blk[E].row, slot = GEO::slot_of(E);
+        const V sel = is_arg<r, slot>();
+        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = op3<TT_MUX>(sel, m2[r][k], m1[r][k]); });
+        su = B::xor_(S[r], sv[E]);
+    }
+
+    // ---- lane permutations of a pi_k block -------------------------------------------------------------------------
+    // packed phi tables of pi_k for this code's M: low (phi mod L) and high (phi / L) parts of the four quarters
+    static constexpr uint32_t phi_lo_lit(int k) { uint32_t v = 0; for (int j = 0; j < 4; ++j) v |= (uint32_t)(phi_of(k, j, M) % L) << (4 * j); return v; }
+    static constexpr uint32_t phi_hi_lit(int k) { uint32_t v = 0; for (int j = 0; j < 4; ++j) v |= (uint32_t)(phi_of(k, j, M) / L) << (5 * j); return v; }
+
+    // pull by VARIABLE lanes from CHECK lanes (u, check -> variable): source lane byte address and rotate-right amount
+    template <int K>
+    BS_FN void perm_c2v(V &addr, V &amt) const
+    {
+        constexpr int TH = theta_of(K);
+        const V sq = B::and_(B::sub(q, B::c(TH)), B::c(3));                       // source quarter of the check
+        const V plo = B::bfe(B::c(phi_lo_lit(K)), B::shl(sq, 2), 4);              // phi(source quarter) mod L
+        const V phi = B::bfe(B::c(phi_hi_lit(K)), B::add(B::shl(sq, 2), sq), 5);  // phi / L
+        const V t = B::sub(ll, plo);
+        const V neg = B::sar(t, 31);                                              // -1 where the lane index wraps
+        const V sl = B::and_(t, B::c(L - 1));
+        addr = B::shl(B::add(cwbase, B::add(B::shl(sq, ilog2c(L)), sl)), 2);
+        amt = B::sub(neg, phi);                                                   // rotl by (phi + wrap) = rotr by -(phi + wrap)
+    }
+    // pull by CHECK lanes from VARIABLE lanes (marginals, variable -> check)
+    template <int K>
+    BS_FN void perm_v2c(V &addr, V &amt) const
+    {
+        constexpr int TH = theta_of(K);
+        const V dq = B::and_(B::add(q, B::c(TH)), B::c(3));                       // quarter of the variable
+        const V plo = B::bfe(B::c(phi_lo_lit(K)), B::shl(q, 2), 4);               // phi(own quarter)
+        const V phi = B::bfe(B::c(phi_hi_lit(K)), B::add(B::shl(q, 2), q), 5);
+        const V t = B::add(ll, plo);
+        const V over = B::shr(t, ilog2c(L));                                      // 1 where the lane index wraps (t < 2L)
+        const V sl = B::and_(t, B::c(L - 1));
+        addr = B::shl(B::add(cwbase, B::add(B::shl(dq, ilog2c(L)), sl)), 2);
+        amt = B::add(phi, over);                                                  // rotr by phi + wrap
+    }
+
+    // ---- one iteration (decoder.rs:380-450), block column by block column -------------------------------------------
+    // `frozen`: all ones in the lanes of codewords that are finished (their hard decisions stay as they are)
+    BS_FN V iteration(B &b, V frozen)
+    {
+        sfor<0, NROWS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            W1[r][0] = B::c(0); W2[r][0] = B::c(0);                                  // key of +127 = 254 (decoder.rs:414-415: maxval)
+            sfor<1, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = B::c(0xFFFFFFFFu); W2[r][k] = B::c(0xFFFFFFFFu); });
+            Sn[r] = B::c(0); Pn[r] = B::c(0);
+            sfor<0, ARG>([&](auto K_) { argn[r][decltype(K_)::value] = B::c(0); });
+        });
+        sfor<0, NCOLS>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            // ---- variable side: marginal of block column c (decoder.rs:382-383, :408) ----
+            V va[8];
+            if constexpr (c < NTX) {
+                sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; va[k] = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256))); });
+            } else {
+                sfor<0, 8>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
+            }
+            sfor<0, NB>([&](auto E_) {
+                constexpr int e = decltype(E_)::value;
+                if constexpr (GEO::P.blk[e].col == c) {
+                    V su, mg[7];
+                    edge_u<e>(su, mg);
+                    if constexpr (!GEO::local(e)) {
+                        V addr, amt;
+                        perm_c2v<GEO::P.blk[e].val>(addr, amt);
+                        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
+                        su = B::rotr(b.bperm(addr, su), amt);
+                    }
+                    A::template sat_addsub<false>(va, su, mg);
+                }
+            });
+            hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
+            // ---- check side of the same edges (decoder.rs:419-447) ----
+            sfor<0, NB>([&](auto E_) {
+                constexpr int e = decltype(E_)::value;
+                if constexpr (GEO::P.blk[e].col == c) {
+                    constexpr int r = GEO::P.blk[e].row, slot = GEO::slot_of(e);
+                    V nv[8];
+                    if constexpr (!GEO::local(e)) {
+                        V addr, amt;
+                        perm_v2c<GEO::P.blk[e].val>(addr, amt);
+                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
+                    } else {
+                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
+                    }
+                    Pn[r] = B::xor_(Pn[r], nv[7]);                                   // parity of the marginals' hard bits (:445-447)
+                    V su, mg[7];
+                    edge_u<e>(su, mg);
+                    A::template sat_addsub<true>(nv, su, mg);                        // new_v_ai = va (-sat) u            (:421)
+                    // self-correction (:422-426): keep unless the old v was non-zero with the other sign
+                    const V keep = op3<0xBF & 0xFF>(nz[e], sv[e], nv[7]);          // placeholder, replaced below
+                    (void)keep;
+                    const V drop = op3<0x60>(nz[e], sv[e], nv[7]);                   // nz & (sv ^ nv7)
+                    sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::andn(nv[k], drop); });       // v = nv & ~drop
+                    sv[e] = nv[7];
+                    nz[e] = op3<TT_OR3>(op3<TT_OR3>(nv[0], nv[1], nv[2]), op3<TT_OR3>(nv[3], nv[4], nv[5]), B::or_(nv[6], nv[7]));
+                    Sn[r] = B::xor_(Sn[r], nv[7]);                                   // product of the signs (:438-441)
+                    // key of |v|: planes 1..7 = v ^ sign, plane 0 = sign -- except for -128, which is +127's key
+                    V key[8];
+                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = B::xor_(nv[k], nv[7]); });
+                    const V all1 = B::and_(op3<TT_AND3>(key[1], key[2], key[3]), op3<TT_AND3>(key[4], key[5], key[6]));
+                    key[0] = op3<0x70>(nv[7], all1, key[7]);                         // sign & ~(all1 & key7)
+                    // two running minima (:430-434)
+                    const V lt1 = A::less_than(key, W1[r]);
+                    const V lt2 = A::less_than(key, W2[r]);
+                    sfor<0, 8>([&](auto K_) {
+                        constexpr int k = decltype(K_)::value;
+                        const V t = op3<TT_MUX>(lt2, key[k], W2[r][k]);
+                        W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], t);
+                        W1[r][k] = op3<TT_MUX>(lt1, key[k], W1[r][k]);
+                    });
+                    sfor<0, ARG>([&](auto K_) {
+                        constexpr int k = decltype(K_)::value;
+                        argn[r][k] = ((slot >> k) & 1) ? B::or_(argn[r][k], lt1) : B::andn(argn[r][k], lt1);
+                    });
+                }
+            });
+        });
+        // ---- the new row state becomes the old one; minima back to magnitudes: (key + 1) >> 1 = (key >> 1) + (key & 1) ----
+        V fail = B::c(0);
+        sfor<0, NROWS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            auto to_mag = [&](const V (&key)[8], V (&mag)[7]) {
+                V c = key[0];
+                sfor<0, 7>([&](auto K_) {
+                    constexpr int k = decltype(K_)::value;
+                    mag[k] = B::xor_(key[k + 1], c);
+                    c = B::and_(key[k + 1], c);
+                });
+            };
+            to_mag(W1[r], m1[r]);
+            to_mag(W2[r], m2[r]);
+            S[r] = Sn[r];
+            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[r][k] = argn[r][k]; });
+            fail = B::or_(fail, Pn[r]);
+        });
+        return fail;                                                                  // non-zero bits = unsatisfied checks (:453)
+    }
+};
+
+static_assert(tt_of([](bool nz, bool sv, bool nv7) { return nz && (sv != nv7); }) == 0x60);
+static_assert(tt_of([](bool s, bool all1, bool k7) { return s && !(all1 && k7); }) == 0x70);
+
+}  // namespace bs
+}  // namespace ldpc
