@@ -57,9 +57,30 @@ BS_FN void sfor(F &&f)
     if constexpr (B0 < E) { f(IC<B0>{}); sfor<B0 + 1, E>(f); }
 }
 
-// truth tables of v_bitop3_b32: bit (a << 2 | b << 1 | c) of the constant is f(a, b, c)
-enum : int { TT_XOR3 = 0x96, TT_MAJ = 0xE8, TT_MUX = 0xCA /* a ? b : c */, TT_OR3 = 0xFE, TT_AND3 = 0x80,
-             TT_A_AND_NOT_B_XOR_C = 0x48 /* unused */ };
+// truth tables of v_bitop3_b32: bit (a << 2 | b << 1 | c) of the constant is f(a, b, c); computed from the function itself
+template <class F>
+constexpr int tt_of(F f)
+{
+    int t = 0;
+    for (int i = 0; i < 8; ++i) t |= (f((bool)((i >> 2) & 1), (bool)((i >> 1) & 1), (bool)(i & 1)) ? 1 : 0) << i;
+    return t;
+}
+inline constexpr int TT_XOR3 = tt_of([](bool a, bool b, bool c) -> bool { return a ^ b ^ c; });
+inline constexpr int TT_MAJ = tt_of([](bool a, bool b, bool c) -> bool { return (a && b) || (c && (a || b)); });
+inline constexpr int TT_MUX = tt_of([](bool a, bool b, bool c) -> bool { return a ? b : c; });
+inline constexpr int TT_OR3 = tt_of([](bool a, bool b, bool c) -> bool { return a || b || c; });
+inline constexpr int TT_AND3 = tt_of([](bool a, bool b, bool c) -> bool { return a && b && c; });
+// overflow of a + x in 8 bits from (a7, sign of x, sum7): same signs in, another sign out
+inline constexpr int TT_OVF = tt_of([](bool a7, bool s, bool sum7) -> bool { return (a7 == s) && (sum7 != a7); });
+// saturated plane 0..6: (ovf, a7, sum) -> ovf ? ~a7 : sum     (0x7F for a >= 0, 0x80 for a < 0)
+inline constexpr int TT_SAT = tt_of([](bool ovf, bool a7, bool sum) -> bool { return ovf ? !a7 : sum; });
+// borrow of a - b, one plane: (b, a, borrow in) -> maj(~a, b, borrow)
+inline constexpr int TT_BORROW = tt_of([](bool b, bool a, bool br) -> bool { return (!a && b) || (br && (!a || b)); });
+// self-correction: (nz, sv, nv7) -> the old v was non-zero and the new sign differs
+inline constexpr int TT_DROP = tt_of([](bool nz, bool sv, bool nv7) -> bool { return nz && (sv != nv7); });
+// plane 0 of the key: (sign, all1, key7) -> sign unless the value is -128
+inline constexpr int TT_KEY0 = tt_of([](bool s, bool all1, bool k7) -> bool { return s && !(all1 && k7); });
+static_assert(TT_XOR3 == 0x96 && TT_MAJ == 0xE8 && TT_MUX == 0xCA && TT_OR3 == 0xFE && TT_AND3 == 0x80);
 
 constexpr int ilog2c(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
@@ -106,14 +127,13 @@ struct Arith {
             c = op3<TT_MAJ>(acc[k], x[k], c);
         });
         sum[7] = op3<TT_XOR3>(acc[7], s, c);                  // the addend's bit 7 is its sign (sign extension)
-        // overflow iff both operands have the same sign and the sum's differs:  (a7 == s) & (sum7 != a7)
-        // as a function of (a7, s, sum7): 001 -> a7=0,s=0,sum7=1: yes; 110 -> a7=1,s=1,sum7=0: yes  => 0x42
-        const V ovf = op3<0x42>(acc[7], s, sum[7]);
+        // overflow iff both operands have the same sign and the sum's differs
+        const V ovf = op3<TT_OVF>(acc[7], s, sum[7]);
         // saturated value: 0x7F if acc >= 0 (a7 = 0), 0x80 if acc < 0: planes 0..6 = ~a7, plane 7 = a7
         const V a7 = acc[7];
         sfor<0, 7>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            acc[k] = op3<0x4E>(ovf, a7, sum[k]);              // ovf ? ~a7 : sum   (a=ovf, b=a7, c=sum): 0x4E
+            acc[k] = op3<TT_SAT>(ovf, a7, sum[k]);
         });
         acc[7] = op3<TT_MUX>(ovf, a7, sum[7]);
     }
@@ -124,25 +144,11 @@ struct Arith {
         V br = B::andn(b[0], a[0]);                           // ~a0 & b0
         sfor<1, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            br = op3<0x8E>(b[k], a[k], br);                   // borrow' = maj(~a, b, borrow)  as f(b, a, br): 0x8E
+            br = op3<TT_BORROW>(b[k], a[k], br);
         });
         return br;
     }
 };
-
-// truth-table self-check helpers (compile time): f(a,b,c) listed for index a<<2|b<<1|c
-constexpr int tt_of(bool (*f)(bool, bool, bool))
-{
-    int t = 0;
-    for (int i = 0; i < 8; ++i) t |= (f((i >> 2) & 1, (i >> 1) & 1, i & 1) ? 1 : 0) << i;
-    return t;
-}
-static_assert(tt_of([](bool a, bool b, bool c) { return a ? b : c; }) == TT_MUX);
-static_assert(tt_of([](bool a, bool b, bool c) { return (a ^ b ^ c); }) == TT_XOR3);
-static_assert(tt_of([](bool a, bool b, bool c) { return (a && b) || (c && (a || b)); }) == TT_MAJ);
-static_assert(tt_of([](bool a7, bool s, bool sum7) { return (a7 == s) && (sum7 != a7); }) == 0x42);
-static_assert(tt_of([](bool ovf, bool a7, bool sum) { return ovf ? !a7 : sum; }) == 0x4E);
-static_assert(tt_of([](bool b, bool a, bool br) { return (!a && b) || (br && (!a || b)); }) == 0x8E);
 
 // ---- the decoder of one group of G codewords, executed by one wave --------------------------------------------------------
 template <int CODE, class B>
@@ -312,9 +318,7 @@ struct Decoder {
                     edge_u<e>(su, mg);
                     A::template sat_addsub<true>(nv, su, mg);                        // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
-                    const V keep = op3<0xBF & 0xFF>(nz[e], sv[e], nv[7]);          // placeholder, replaced below
-                    (void)keep;
-                    const V drop = op3<0x60>(nz[e], sv[e], nv[7]);                   // nz & (sv ^ nv7)
+                    const V drop = op3<TT_DROP>(nz[e], sv[e], nv[7]);
                     sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::andn(nv[k], drop); });       // v = nv & ~drop
                     sv[e] = nv[7];
                     nz[e] = op3<TT_OR3>(op3<TT_OR3>(nv[0], nv[1], nv[2]), op3<TT_OR3>(nv[3], nv[4], nv[5]), B::or_(nv[6], nv[7]));
@@ -323,7 +327,7 @@ struct Decoder {
                     V key[8];
                     sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = B::xor_(nv[k], nv[7]); });
                     const V all1 = B::and_(op3<TT_AND3>(key[1], key[2], key[3]), op3<TT_AND3>(key[4], key[5], key[6]));
-                    key[0] = op3<0x70>(nv[7], all1, key[7]);                         // sign & ~(all1 & key7)
+                    key[0] = op3<TT_KEY0>(nv[7], all1, key[7]);
                     // two running minima (:430-434)
                     const V lt1 = A::less_than(key, W1[r]);
                     const V lt2 = A::less_than(key, W2[r]);
@@ -362,8 +366,118 @@ struct Decoder {
     }
 };
 
-static_assert(tt_of([](bool nz, bool sv, bool nv7) { return nz && (sv != nv7); }) == 0x60);
-static_assert(tt_of([](bool s, bool all1, bool k7) { return s && !(all1 && k7); }) == 0x70);
+// ---- driver: one wave decodes group after group of G codewords ---------------------------------------------------------------
+// llrs [batch][N] i8, output [batch][NP/8] MSB first, iters [batch], success [batch]; `group` = index of the group of G frames.
+// (Lane offsets are relative to the group's first frame, so they fit 32 bits whatever the batch.)
+template <int CODE, class B>
+BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint32_t *iters_all, uint8_t *success_all, uint32_t batch,
+                        uint32_t maxiters, uint32_t group)
+{
+    using GEO = Geo<CODE>;
+    using V = typename B::V;
+    constexpr int M = GEO::M, N = GEO::N, L = GEO::L, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS, Q = GEO::Q;
+    Decoder<CODE, B> d;
+    d.init_lane(b);
+    d.reset_state();
+    const V lane = d.lane;
+    const V cw = B::shr(lane, ilog2c(W));                                    // codeword of the lane inside the group (0 for W = 64)
+    const V lw = B::and_(lane, B::c(W - 1));                                 // lane inside the codeword
+    const int8_t *llrs = llrs_all + (size_t)group * G * GEO::N;
+    uint8_t *output = output_all + (size_t)group * G * GEO::OUT_LEN;
+    uint32_t *iters = iters_all + (size_t)group * G;
+    uint8_t *success = success_all + (size_t)group * G;
+    const V frame = cw;                                                      // frame index relative to the group's first
+    const V valid = B::less_u(B::add(B::c(group * (uint32_t)G), cw), B::c(batch));      // all ones where the lane's codeword exists
+    const uint64_t valid_mask = b.ballot(valid);
+
+    // ---- LLRs: 2048 raw bytes of block column c (32 per lane) -> staging slab -> 8 bit planes per lane ----
+    sfor<0, NTX>([&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        const V src = B::add(B::mul_u(frame, (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));        // byte offset into llrs (batch * N < 2^32: launcher)
+        sfor<0, 8>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i)), valid), valid);
+            b.lds_write32(B::add(B::shl(lane, 5), B::c(GEO::LDS_STAGE + 4 * i)), w);
+        });
+        // lane (cw, q, ll) gathers the bytes of its 32 indices: q * Q + ll + L * bit; dword dd holds bits dd, 8 + dd, 16 + dd, 24 + dd
+        const V base = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), B::add(d.ll, B::c(GEO::LDS_STAGE)));
+        V X[8];
+        sfor<0, 8>([&](auto D_) {
+            constexpr int dd = decltype(D_)::value;
+            V x = b.lds_read_u8(B::add(base, B::c(L * dd)));
+            x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (8 + dd)))), 8));
+            x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (16 + dd)))), 16));
+            x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (24 + dd)))), 24));
+            X[dd] = x;
+        });
+        // 8 x 8 bit-matrix transpose inside every byte lane: afterwards X[p] byte y bit dd = bit p of LLR (8 y + dd)
+        auto stage = [&](auto S_, uint32_t mask) {
+            constexpr int s = decltype(S_)::value;
+            sfor<0, 8>([&](auto D_) {
+                constexpr int dd = decltype(D_)::value;
+                if constexpr ((dd & s) == 0) {
+                    const V t = B::and_(B::xor_(B::shr(X[dd], s), X[dd + s]), B::c(mask));
+                    X[dd + s] = B::xor_(X[dd + s], t);
+                    X[dd] = B::xor_(X[dd], B::shl(t, s));
+                }
+            });
+        };
+        stage(IC<4>{}, 0x0F0F0F0Fu);
+        stage(IC<2>{}, 0x33333333u);
+        stage(IC<1>{}, 0x55555555u);
+        sfor<0, 8>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);
+        });
+    });
+
+    // ---- iterations (decoder.rs:380-464): the codewords of the wave run in lockstep, a finished one is frozen ----
+    uint64_t frozen_mask = ~valid_mask;
+    V iters_v = B::c(maxiters), ok_v = B::c(0);
+    for (uint32_t it = 0; it < maxiters && frozen_mask != ~0ull; ++it) {
+        const V frozen = b.plane_of(frozen_mask);
+        const V fail = d.iteration(b, frozen);
+        const uint64_t unsat_lanes = b.ballot(fail);
+        uint64_t unsat = 0;
+        if constexpr (W == 64) unsat = unsat_lanes ? ~0ull : 0ull;
+        else {
+            constexpr uint64_t gm = (1ull << W) - 1;
+            for (int g = 0; g < G; ++g)
+                if ((unsat_lanes >> (g * W)) & gm) unsat |= gm << (g * W);
+        }
+        const uint64_t newly = ~frozen_mask & ~unsat;                          // satisfied for the first time: (true, it)  (:453-463)
+        const V nw = b.plane_of(newly);
+        iters_v = B::template bitop3<TT_MUX>(nw, B::c(it), iters_v);
+        ok_v = B::or_(ok_v, B::and_(nw, B::c(1)));
+        frozen_mask |= newly;
+    }
+
+    // ---- hard decisions, MSB first (decoder.rs:455-461 / :467-473): plane -> LDS -> one dword of 32 consecutive bits per lane ----
+    sfor<0, NCOLS>([&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), d.hard[c]);
+    });
+    const V b0 = B::shl(d.ll, 5 - ilog2c(L));                                 // first bit of this lane's 32 indices: 32 ll / L
+    const V qbase = B::shl(B::add(d.cwbase, B::shl(d.q, ilog2c(L))), 2);     // byte offset of the quarter's first lane
+    sfor<0, NCOLS>([&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        V out = B::c(0);
+        sfor<0, L>([&](auto LL_) {
+            constexpr int l2 = decltype(LL_)::value;
+            const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(GEO::LDS_HARD + c * 256 + 4 * l2))), b0);
+            sfor<0, 32 / L>([&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                constexpr int t = l2 + L * k;                                     // index inside the 32, MSB first inside its byte
+                constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
+                out = B::or_(out, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
+            });
+        });
+        b.gstore32(output, B::add(B::mul_u(frame, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw, 2))), out, valid);
+    });
+    const V first = B::and_(valid, B::eq(lw, B::c(0)));
+    b.gstore32(iters, B::shl(frame, 2), iters_v, first);
+    b.gstore8(success, frame, ok_v, first);
+}
 
 }  // namespace bs
 }  // namespace ldpc

@@ -1,0 +1,90 @@
+// decode_ms_bs.hip -- gfx950 instantiation of the bit-sliced i8 min-sum decoder (decode_ms_bitslice.hpp;
+// decode_ms::<i8>, /root/reference/src/decoder.rs:42-50, :347-475) for the TM codes, and its launcher.
+//
+// One wave per workgroup, one group of G = 64 / (M/32) codewords per workgroup: a codeword never leaves its wave, so the
+// kernel has no barrier, and the hardware dispatcher is the work queue (decodes take 3..25 iterations; a finished wave
+// makes room for the next group at once).  LDS per workgroup: the LLRs as bit planes (n bytes per codeword, the size of
+// the raw LLRs), a 2 KB staging slab, one word per lane and block column for the hard decisions.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "decode_ms_bitslice.hpp"
+
+namespace ldpc {
+namespace bs {
+
+struct HipBackend {
+    using V = uint32_t;
+    char *lds;
+
+    static BS_FN V c(uint32_t x) { return x; }
+    BS_FN V lane() const { return threadIdx.x & 63u; }
+    template <int TT> static BS_FN V bitop3(V a, V b, V cc) { return (V)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)cc, TT); }
+    static BS_FN V and_(V a, V b) { return a & b; }
+    static BS_FN V or_(V a, V b) { return a | b; }
+    static BS_FN V xor_(V a, V b) { return a ^ b; }
+    static BS_FN V andn(V a, V b) { return a & ~b; }
+    static BS_FN V not_(V a) { return ~a; }
+    static BS_FN V add(V a, V b) { return a + b; }
+    static BS_FN V sub(V a, V b) { return a - b; }
+    static BS_FN V mul_u(V a, uint32_t k) { return a * k; }
+    static BS_FN V shl(V a, int s) { return a << s; }
+    static BS_FN V shr(V a, int s) { return a >> s; }
+    static BS_FN V sar(V a, int s) { return (V)((int32_t)a >> s); }
+    static BS_FN V shr_v(V a, V s) { return a >> (s & 31u); }
+    static BS_FN V bfe(V v, V off, int width) { return __builtin_amdgcn_ubfe(v, off, (uint32_t)width); }
+    static BS_FN V rotr(V x, V amt) { return __builtin_amdgcn_alignbit(x, x, amt); }
+    static BS_FN V less_u(V a, V b) { return a < b ? 0xFFFFFFFFu : 0u; }
+    static BS_FN V eq(V a, V b) { return a == b ? 0xFFFFFFFFu : 0u; }
+    BS_FN V bperm(V addr, V x) const { return (V)__builtin_amdgcn_ds_bpermute((int)addr, (int)x); }
+    BS_FN V lds_read32(V addr) const { return *reinterpret_cast<const uint32_t *>(lds + addr); }
+    BS_FN void lds_write32(V addr, V v) { *reinterpret_cast<uint32_t *>(lds + addr) = v; }
+    BS_FN V lds_read_u8(V addr) const { return *reinterpret_cast<const uint8_t *>(lds + addr); }
+    static BS_FN V gload32(const void *p, V off, V pred)
+    {
+        return pred ? *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off) : 0u;
+    }
+    static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off) = v; }
+    static BS_FN void gstore8(void *p, V off, V v, V pred) { if (pred) static_cast<uint8_t *>(p)[off] = (uint8_t)v; }
+    static BS_FN uint64_t ballot(V x) { return __ballot(x != 0u); }
+    BS_FN V plane_of(uint64_t m) const { return ((m >> (threadIdx.x & 63u)) & 1ull) ? 0xFFFFFFFFu : 0u; }
+};
+
+template <int CODE>
+__global__ void __launch_bounds__(64, 2)         // two waves per SIMD: at most 256 registers
+decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters,
+                    uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t ngroups)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Geo<CODE>::LDS_BYTES];
+    HipBackend b{lds};
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g);
+}
+
+template <int CODE>
+hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
+{
+    constexpr int G = Geo<CODE>::G;
+    if (batch == 0) return hipSuccess;
+    if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const size_t groups = (batch + G - 1) / G;
+    const size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
+    hipLaunchKernelGGL((decode_ms_bs_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
+                       (uint32_t)groups);
+    return hipGetLastError();
+}
+
+}  // namespace bs
+
+// i8 LLRs through the bit-sliced kernel; hipErrorInvalidConfiguration for the codes it is not built for (the TC codes: their
+// circulants are not quarter-wise rotations).  llrs 4-byte aligned, output 4-byte aligned.
+hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                      uint32_t maxiters, hipStream_t stream)
+{
+    switch (code) {
+        case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+
+}  // namespace ldpc

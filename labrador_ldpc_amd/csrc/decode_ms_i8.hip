@@ -16,12 +16,21 @@ namespace ldpc {
     X(TM6144, int8_t, 1, 2) \
     X(TM8192, int8_t, 2)
 
+// the bit-sliced kernel (decode_ms_bs.hip): `variant` 64
+hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                      uint32_t maxiters, hipStream_t stream);
+constexpr int VARIANT_BITSLICE = 64;
+
 template <>
 hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, uint8_t *output,
                                     uint32_t *iters, uint8_t *success, size_t batch,
                                     uint32_t maxiters, hipStream_t stream)
 {
     LDPC_SPLIT_VARIANT();
+    if (variant == VARIANT_BITSLICE) {
+        if ((uintptr_t)llrs % 4) return hipErrorInvalidConfiguration;        // (its loads are dwords)
+        return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
+    }
     // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
         if (code == TM8192) return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);

@@ -1,0 +1,110 @@
+// CPU emulation of the bit-sliced i8 decoder (labrador_ldpc_amd/csrc/decode_ms_bitslice.hpp): the SAME source text the
+// gfx950 kernel is compiled from, instantiated with a backend whose "wave register" is an array of 64 lanes and whose
+// cross-lane / LDS / memory operations are plain loops.  Test infrastructure (tests/test_bitslice_emu.py compares its
+// results with the oracle on the CPU, so the formulation -- layout, lane permutations, plane arithmetic, compressed row
+// state -- is validated without a GPU); it is not part of the product and nothing in labrador_ldpc_amd/ links it.
+//   g++ -O2 -std=c++20 -shared -fPIC -Ilabrador_ldpc_amd/csrc tests/c/bitslice_emu.cpp -o build/libbitslice_emu.so
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define BS_FN inline
+#include "decode_ms_bitslice.hpp"
+
+namespace {
+
+struct Vec {
+    uint32_t l[64];
+};
+
+struct EmuBackend {
+    using V = Vec;
+    std::vector<uint8_t> lds;
+    explicit EmuBackend(size_t lds_bytes) : lds(lds_bytes, 0xA5) {}
+
+    template <class F> static V map1(const V &a, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i]); return r; }
+    template <class F> static V map2(const V &a, const V &b, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i], b.l[i]); return r; }
+
+    static V c(uint32_t x) { V r; for (auto &e : r.l) e = x; return r; }
+    V lane() const { V r; for (int i = 0; i < 64; ++i) r.l[i] = (uint32_t)i; return r; }
+    template <int TT> static V bitop3(const V &a, const V &b, const V &cc)
+    {
+        V r;
+        for (int i = 0; i < 64; ++i) {
+            uint32_t o = 0;
+            for (int m = 0; m < 8; ++m)
+                if ((TT >> m) & 1) o |= ((m & 4) ? a.l[i] : ~a.l[i]) & ((m & 2) ? b.l[i] : ~b.l[i]) & ((m & 1) ? cc.l[i] : ~cc.l[i]);
+            r.l[i] = o;
+        }
+        return r;
+    }
+    static V and_(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x & y; }); }
+    static V or_(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x | y; }); }
+    static V xor_(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x ^ y; }); }
+    static V andn(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x & ~y; }); }
+    static V not_(const V &a) { return map1(a, [](uint32_t x) { return ~x; }); }
+    static V add(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x + y; }); }
+    static V sub(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x - y; }); }
+    static V mul_u(const V &a, uint32_t k) { return map1(a, [k](uint32_t x) { return x * k; }); }
+    static V shl(const V &a, int s) { return map1(a, [s](uint32_t x) { return x << s; }); }
+    static V shr(const V &a, int s) { return map1(a, [s](uint32_t x) { return x >> s; }); }
+    static V sar(const V &a, int s) { return map1(a, [s](uint32_t x) { return (uint32_t)((int32_t)x >> s); }); }
+    static V shr_v(const V &a, const V &s) { return map2(a, s, [](uint32_t x, uint32_t y) { return x >> (y & 31); }); }
+    static V bfe(const V &v, const V &off, int width) { return map2(v, off, [width](uint32_t x, uint32_t o) { return (x >> (o & 31)) & ((1u << width) - 1); }); }
+    static V rotr(const V &x, const V &amt) { return map2(x, amt, [](uint32_t v, uint32_t a) { a &= 31; return a ? (v >> a) | (v << (32 - a)) : v; }); }
+    static V less_u(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x < y ? 0xFFFFFFFFu : 0u; }); }
+    static V eq(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x == y ? 0xFFFFFFFFu : 0u; }); }
+    V bperm(const V &addr, const V &x) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = x.l[(addr.l[i] >> 2) & 63]; return r; }
+    V lds_read32(const V &addr) const { V r; for (int i = 0; i < 64; ++i) std::memcpy(&r.l[i], &lds.at(addr.l[i]), 4), (void)lds.at(addr.l[i] + 3); return r; }
+    void lds_write32(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { (void)lds.at(addr.l[i] + 3); std::memcpy(&lds.at(addr.l[i]), &v.l[i], 4); } }
+    V lds_read_u8(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds.at(addr.l[i]); return r; }
+    static V gload32(const void *p, const V &off, const V &pred)
+    {
+        V r;
+        for (int i = 0; i < 64; ++i) { r.l[i] = 0; if (pred.l[i]) std::memcpy(&r.l[i], (const char *)p + off.l[i], 4); }
+        return r;
+    }
+    static void gstore32(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) std::memcpy((char *)p + off.l[i], &v.l[i], 4); }
+    static void gstore8(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) ((uint8_t *)p)[off.l[i]] = (uint8_t)v.l[i]; }
+    static uint64_t ballot(const V &x) { uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(x.l[i] != 0) << i; return m; }
+    static V plane_of(uint64_t m) { V r; for (int i = 0; i < 64; ++i) r.l[i] = ((m >> i) & 1) ? 0xFFFFFFFFu : 0u; return r; }
+};
+
+template <int CODE>
+int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    using GEO = ldpc::bs::Geo<CODE>;
+    const size_t groups = (batch + GEO::G - 1) / GEO::G;
+    for (size_t g = 0; g < groups; ++g) {
+        EmuBackend b(GEO::LDS_BYTES);
+        ldpc::bs::decode_group<CODE, EmuBackend>(b, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bs_emu_decode(int code, const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    switch (code) {
+        case ldpc::TM1280: return run<ldpc::TM1280>(llrs, out, iters, ok, batch, maxiters);
+        case ldpc::TM1536: return run<ldpc::TM1536>(llrs, out, iters, ok, batch, maxiters);
+        case ldpc::TM2048: return run<ldpc::TM2048>(llrs, out, iters, ok, batch, maxiters);
+        case ldpc::TM5120: return run<ldpc::TM5120>(llrs, out, iters, ok, batch, maxiters);
+        case ldpc::TM6144: return run<ldpc::TM6144>(llrs, out, iters, ok, batch, maxiters);
+        case ldpc::TM8192: return run<ldpc::TM8192>(llrs, out, iters, ok, batch, maxiters);
+        default: return -1;
+    }
+}
+extern "C" int bs_emu_group(int code)
+{
+    switch (code) {
+        case ldpc::TM1280: return ldpc::bs::Geo<ldpc::TM1280>::G;
+        case ldpc::TM1536: return ldpc::bs::Geo<ldpc::TM1536>::G;
+        case ldpc::TM2048: return ldpc::bs::Geo<ldpc::TM2048>::G;
+        case ldpc::TM5120: return ldpc::bs::Geo<ldpc::TM5120>::G;
+        case ldpc::TM6144: return ldpc::bs::Geo<ldpc::TM6144>::G;
+        case ldpc::TM8192: return ldpc::bs::Geo<ldpc::TM8192>::G;
+        default: return 0;
+    }
+}

@@ -1,0 +1,89 @@
+"""The bit-sliced i8 decoder (labrador_ldpc_amd/csrc/decode_ms_bitslice.hpp) validated WITHOUT a GPU: tests/c/bitslice_emu.cpp
+instantiates the kernel's own source text with a backend whose wave register is an array of 64 lanes (ds_bpermute, LDS and global
+accesses as plain loops) and this file compares its results -- hard bits, iteration counts, success flags -- with the CPU oracle and
+with the frozen i8 golden files, for the six TM codes (the layout is built on their quarter-wise permutations pi_k).  What it
+pins: the index -> (lane, bit) layout and its lane permutations / word rotations, the plane arithmetic (saturating add / sub,
+the sign-split key of |v|, the two running minima), the compressed row state, the LLR transposition and the output packing,
+codewords of one wave finishing in different iterations.  The GPU tests then only have to show that gfx950 executes the same
+text the same way (tests/test_gpu_bitslice.py)."""
+import ctypes
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TM = ["TM1280", "TM1536", "TM2048", "TM5120", "TM6144", "TM8192"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = os.path.join(ROOT, "build", "libbitslice_emu.so")
+    src = [os.path.join(ROOT, "tests", "c", "bitslice_emu.cpp"), os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "decode_ms_bitslice.hpp"),
+           os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "codes.hpp")]
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in src):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "labrador_ldpc_amd", "csrc"), src[0], "-o", lib])
+    L = ctypes.CDLL(lib)
+    L.bs_emu_decode.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+
+    def decode(code, llrs, maxiters):
+        llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+        B = llrs.shape[0]
+        out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
+        it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
+        assert L.bs_emu_decode(code, llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
+        return out, it, ok
+    decode.group = lambda code: L.bs_emu_group(code)
+    return decode
+
+
+def _same(emu, code, llrs, maxiters):
+    o, i, k = emu(code, llrs, maxiters)
+    oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs, maxiters)
+    bad = np.nonzero((o != oc).any(axis=1) | (i != ic) | (k != kc))[0]
+    assert bad.size == 0, f"frames {bad.tolist()[:8]} differ (iters {i[bad][:8].tolist()} vs {ic[bad][:8].tolist()})"
+    return i, k
+
+
+@pytest.mark.parametrize("name", TM)
+def test_emulated_kernel_equals_the_oracle_on_awgn_frames(emu, name):
+    code = oracle.CODES.index(name)
+    rng = np.random.default_rng(100 + code)
+    # converging early / late / never, at the usual scale and at a saturating one; odd frame counts leave the last wave part-filled
+    for ebn0, scale, lim, frames in ((3.5 if name in ("TM1280", "TM5120") else 2.5, 8.0, 31, 2 * emu.group(code) + 1), (1.0, 30.0, 127, 3), (4.5, 16.0, 127, 5)):
+        llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, np.int8, scale=scale, lim=lim)
+        for maxiters in (0, 3, 25):
+            it, ok = _same(emu, code, llrs, maxiters)
+    assert ok.all() and len(set(it.tolist())) > 1        # (the last set at 25: everything converges, after different numbers of iterations)
+
+
+@pytest.mark.parametrize("name", ["TM1280", "TM2048", "TM6144"])
+def test_emulated_kernel_on_corner_inputs(emu, name):
+    code = oracle.CODES.index(name)
+    N = oracle.n(code)
+    rng = np.random.default_rng(11)
+    frames = [np.zeros(N, np.int8), np.full(N, -128, np.int8), np.full(N, 127, np.int8), rng.integers(-128, 128, N).astype(np.int8),
+              rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)]
+    base, _ = oracle.awgn_llrs(code, rng, 3, 3.0, np.int8, scale=60.0, lim=127)
+    spiked = base.copy()
+    spiked[:, ::7] = -128                                   # |-128| = 127 (decoder.rs:46) inside otherwise decodable frames
+    llrs = np.stack(frames + list(spiked) + list(base))
+    for maxiters in (25, 1, 2, 60):
+        _same(emu, code, llrs, maxiters)
+
+
+def test_emulated_kernel_reproduces_the_i8_golden_files(emu):
+    """tests/golden/awgn_<code>_i8.npz: frozen frames with the results both restatements agreed on -- no oracle in this loop."""
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "awgn_TM*_i8.npz")))
+    assert len(files) == 6
+    for f in files:
+        z = np.load(f)
+        code = oracle.CODES.index(os.path.basename(f).split("_")[1])
+        for maxiters in (25, 4, 0):
+            o, i, k = emu(code, z["llrs"], maxiters)
+            assert (o == z[f"output_{maxiters}"]).all() and (i == z[f"iters_{maxiters}"]).all() and (k == z[f"success_{maxiters}"]).all(), (f, maxiters)

@@ -1,0 +1,74 @@
+"""The bit-sliced i8 kernel (csrc/decode_ms_bitslice.hpp, `variant` 64) on the GPU against the oracle and the frozen i8 golden
+files: the CPU tests (tests/test_bitslice_emu.py) validate the formulation by running the kernel's source text lane by lane;
+here gfx950 executes the same text -- v_bitop3_b32, ds_bpermute_b32, v_alignbit_b32 -- and must return the same bytes, through the
+device-pointer and the host-pointer entry points, for whole and part-filled waves, and equal to the default i8 kernels."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from labrador_ldpc_amd import LDPCCode
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BS = 64                                                       # `variant` of the bit-sliced kernel
+CODES = [LDPCCode.TM2048, LDPCCode.TM8192]
+
+
+def _same(code, llrs, maxiters):
+    o, i, k = code.decode_ms_batch(llrs, maxiters, variant=BS)
+    oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs, maxiters)
+    bad = np.nonzero((o != oc).any(axis=1) | (i != ic) | (k != kc))[0]
+    assert bad.size == 0, f"frames {bad.tolist()[:8]} differ (iters {i[bad][:8].tolist()} vs {ic[bad][:8].tolist()})"
+    return i, k
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_bitsliced_kernel_equals_the_oracle(code):
+    rng = np.random.default_rng(500 + int(code))
+    for ebn0, scale, lim, frames in ((2.0, 8.0, 31, 257), (1.0, 30.0, 127, 33), (4.5, 16.0, 127, 64), (2.5, 8.0, 31, 1)):
+        llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, np.int8, scale=scale, lim=lim)
+        for maxiters in (25, 3, 0, 60):
+            _same(code, llrs, maxiters)
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_bitsliced_kernel_on_corner_inputs(code):
+    N = code.n()
+    rng = np.random.default_rng(11)
+    frames = [np.zeros(N, np.int8), np.full(N, -128, np.int8), np.full(N, 127, np.int8), rng.integers(-128, 128, N).astype(np.int8),
+              rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)]
+    base, _ = oracle.awgn_llrs(code, rng, 3, 3.0, np.int8, scale=60.0, lim=127)
+    spiked = base.copy()
+    spiked[:, ::7] = -128
+    llrs = np.stack(frames + list(spiked) + list(base))
+    for maxiters in (25, 1, 2):
+        _same(code, llrs, maxiters)
+
+
+def test_bitsliced_kernel_reproduces_the_i8_golden_files():
+    for code in CODES:
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"awgn_{code.name}_i8.npz"))
+        for maxiters in (25, 4, 0):
+            o, i, k = code.decode_ms_batch(z["llrs"], maxiters, variant=BS)
+            assert (o == z[f"output_{maxiters}"]).all() and (i == z[f"iters_{maxiters}"]).all() and (k == z[f"success_{maxiters}"]).all()
+
+
+@pytest.mark.parametrize("code", CODES)
+def test_bitsliced_kernel_equals_the_default_i8_kernel_on_a_large_batch(code):
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    pool = np.zeros((16, code.n() // 8), np.uint8)
+    for i in range(16):
+        code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
+    frames = 100003                                             # odd: the last wave of TM2048 holds three codewords
+    sigma = float(np.sqrt(1.0 / (2.0 * 0.5 * 10.0 ** 0.2)))
+    llrs = code.awgn_frames(torch.from_numpy(pool).to(dev), frames, sigma, seed=99, dtype="i8")
+    a = code.decode_ms_batch(llrs, 25)
+    b = code.decode_ms_batch(llrs, 25, variant=BS)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert 0.5 < float(a[2].float().mean()) <= 1.0

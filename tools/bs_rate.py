@@ -1,0 +1,31 @@
+"""Rate of the bit-sliced i8 kernel (`variant` 64) against the default i8 kernel and the f32 kernel, same frames, same process.
+    python tools/bs_rate.py [frames]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from labrador_ldpc_amd import LDPCCode
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+dev = torch.device("cuda", 0)
+for code, ebn0 in ((LDPCCode.TM8192, 2.0), (LDPCCode.TM2048, 2.0), (LDPCCode.TM2048, 2.5)):
+    rng = np.random.default_rng(1)
+    pool = np.zeros((64, code.n() // 8), np.uint8)
+    for i in range(64):
+        code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
+    sigma = float(np.sqrt(1.0 / (2.0 * 0.5 * 10.0 ** (ebn0 / 10.0))))
+    fr = frames if code == LDPCCode.TM8192 else frames * 4
+    llrs8 = code.awgn_frames(torch.from_numpy(pool).to(dev), fr, sigma, seed=5, dtype="i8")
+    llrs32 = code.awgn_frames(torch.from_numpy(pool).to(dev), fr, sigma, seed=5, dtype="f32")
+    res = {}
+    for name, l, variant in (("i8 default", llrs8, 0), ("i8 bit-sliced", llrs8, 64), ("f32 default", llrs32, 0)):
+        out = code.decode_ms_batch(l, 25, variant=variant)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            out = code.decode_ms_batch(l, 25, variant=variant)
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+        res[name] = out
+        print(f"{code.name} {ebn0} dB {fr} frames  {name:14s} {fr / ms / 1e3:8.2f} M codewords/s  {ms:8.2f} ms  mean iters {float(out[1].double().mean()):.2f}", flush=True)
+    same = all(torch.equal(x, y) for x, y in zip(res["i8 default"], res["i8 bit-sliced"]))
+    print("   bit-sliced == default i8:", same, flush=True)
