@@ -78,6 +78,8 @@ inline constexpr int TT_SAT = tt_of([](bool ovf, bool a7, bool sum) -> bool { re
 inline constexpr int TT_BORROW = tt_of([](bool b, bool a, bool br) -> bool { return (!a && b) || (br && (!a || b)); });
 // self-correction: (nz, sv, nv7) -> the old v was non-zero and the new sign differs
 inline constexpr int TT_DROP = tt_of([](bool nz, bool sv, bool nv7) -> bool { return nz && (sv != nv7); });
+// plane k + 1 of the key of v = drop ? 0 : nv:  (nv_k, nv7, drop) -> (nv_k ^ nv7) & ~drop
+inline constexpr int TT_KEYBIT = tt_of([](bool x, bool s, bool drop) -> bool { return (x != s) && !drop; });
 // plane 0 of the key: (sign, all1, key7) -> sign unless the value is -128
 inline constexpr int TT_KEY0 = tt_of([](bool s, bool all1, bool k7) -> bool { return s && !(all1 && k7); });
 static_assert(TT_XOR3 == 0x96 && TT_MAJ == 0xE8 && TT_MUX == 0xCA && TT_OR3 == 0xFE && TT_AND3 == 0x80);
@@ -102,8 +104,13 @@ struct Geo {
     // slot of block b inside its row (the arg-min identifier)
     static constexpr int slot_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += P.blk[i].row == P.blk[b].row; return s; }
     static constexpr bool local(int b) { return P.blk[b].kind == BLK_I && P.blk[b].val == 0; }
-    // LDS words: LLR planes [NTX][8][64], a 2048-byte staging slab, hard-decision words [NCOLS][64]
-    static constexpr int LDS_LLR = 0, LDS_STAGE = NTX * 8 * 64 * 4, LDS_HARD = LDS_STAGE + 2048, LDS_BYTES = LDS_HARD + NCOLS * 64 * 4;
+    // ordinal of block b among the exchanged (pi_k) blocks
+    static constexpr int exch_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += local(i) ? 0 : 1; return s; }
+    static constexpr int NX = exch_of(NB);
+    // LDS words: LLR planes [NTX][8][64], a 2048-byte staging slab, hard-decision words [NCOLS][64], and the lane permutations of
+    // the exchanged blocks [NX][2 directions][64] (source lane address | rotate amount << 8; constant for the kernel's lifetime)
+    static constexpr int LDS_LLR = 0, LDS_STAGE = NTX * 8 * 64 * 4, LDS_HARD = LDS_STAGE + 2048, LDS_PERM = LDS_HARD + NCOLS * 64 * 4,
+                         LDS_BYTES = LDS_PERM + NX * 2 * 64 * 4;
 };
 
 // ---- arithmetic on bit planes -------------------------------------------------------------------------------------------
@@ -265,6 +272,22 @@ struct Decoder {
         amt = B::add(phi, over);                                                  // rotr by phi + wrap
     }
 
+    // The permutations depend on the lane only: computed once per kernel into LDS.  ds_bpermute_b32 reads bits 7:2 of its address
+    // and v_alignbit_b32 bits 4:0 of its shift, so one word carries both: address | amount << 8.
+    BS_FN void init_perm_tables(B &b) const
+    {
+        sfor<0, NB>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            if constexpr (!GEO::local(e)) {
+                V addr, amt;
+                perm_c2v<GEO::P.blk[e].val>(addr, amt);
+                b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 0) * 256)), B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
+                perm_v2c<GEO::P.blk[e].val>(addr, amt);
+                b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 1) * 256)), B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
+            }
+        });
+    }
+
     // ---- one iteration (decoder.rs:380-450), block column by block column -------------------------------------------
     // `frozen`: all ones in the lanes of codewords that are finished (their hard decisions stay as they are)
     BS_FN V iteration(B &b, V frozen)
@@ -278,6 +301,7 @@ struct Decoder {
         });
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
+            B::fence();            // keep the compiler from hoisting the next column's loads over this one's arithmetic (register pressure)
             // ---- variable side: marginal of block column c (decoder.rs:382-383, :408) ----
             V va[8];
             if constexpr (c < NTX) {
@@ -291,12 +315,13 @@ struct Decoder {
                     V su, mg[7];
                     edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
-                        V addr, amt;
-                        perm_c2v<GEO::P.blk[e].val>(addr, amt);
+                        const V addr = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 0) * 256)));
+                        const V amt = B::shr(addr, 8);
                         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
                         su = B::rotr(b.bperm(addr, su), amt);
                     }
                     A::template sat_addsub<false>(va, su, mg);
+                    B::fence();
                 }
             });
             hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
@@ -307,8 +332,8 @@ struct Decoder {
                     constexpr int r = GEO::P.blk[e].row, slot = GEO::slot_of(e);
                     V nv[8];
                     if constexpr (!GEO::local(e)) {
-                        V addr, amt;
-                        perm_v2c<GEO::P.blk[e].val>(addr, amt);
+                        const V addr = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 1) * 256)));
+                        const V amt = B::shr(addr, 8);
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
                     } else {
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
@@ -319,15 +344,16 @@ struct Decoder {
                     A::template sat_addsub<true>(nv, su, mg);                        // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
                     const V drop = op3<TT_DROP>(nz[e], sv[e], nv[7]);
-                    sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::andn(nv[k], drop); });       // v = nv & ~drop
-                    sv[e] = nv[7];
-                    nz[e] = op3<TT_OR3>(op3<TT_OR3>(nv[0], nv[1], nv[2]), op3<TT_OR3>(nv[3], nv[4], nv[5]), B::or_(nv[6], nv[7]));
-                    Sn[r] = B::xor_(Sn[r], nv[7]);                                   // product of the signs (:438-441)
+                    // v = drop ? 0 : nv is never formed: its sign, its key and "v != 0" follow from nv and drop directly.
                     // key of |v|: planes 1..7 = v ^ sign, plane 0 = sign -- except for -128, which is +127's key
                     V key[8];
-                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = B::xor_(nv[k], nv[7]); });
+                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = op3<TT_KEYBIT>(nv[k], nv[7], drop); });
+                    const V vs = B::andn(nv[7], drop);                               // sign of the new v
                     const V all1 = B::and_(op3<TT_AND3>(key[1], key[2], key[3]), op3<TT_AND3>(key[4], key[5], key[6]));
-                    key[0] = op3<TT_KEY0>(nv[7], all1, key[7]);
+                    key[0] = op3<TT_KEY0>(vs, all1, key[7]);
+                    sv[e] = vs;
+                    nz[e] = op3<TT_OR3>(op3<TT_OR3>(key[1], key[2], key[3]), op3<TT_OR3>(key[4], key[5], key[6]), B::or_(key[7], vs));
+                    Sn[r] = B::xor_(Sn[r], vs);                                      // product of the signs (:438-441)
                     // two running minima (:430-434)
                     const V lt1 = A::less_than(key, W1[r]);
                     const V lt2 = A::less_than(key, W2[r]);
@@ -341,6 +367,7 @@ struct Decoder {
                         constexpr int k = decltype(K_)::value;
                         argn[r][k] = ((slot >> k) & 1) ? B::or_(argn[r][k], lt1) : B::andn(argn[r][k], lt1);
                     });
+                    B::fence();
                 }
             });
         });
@@ -365,6 +392,15 @@ struct Decoder {
         return fail;                                                                  // non-zero bits = unsatisfied checks (:453)
     }
 };
+
+// once per kernel (per wave): the lane permutation tables
+template <int CODE, class B>
+BS_FN void init_kernel(B &b)
+{
+    Decoder<CODE, B> d;
+    d.init_lane(b);
+    d.init_perm_tables(b);
+}
 
 // ---- driver: one wave decodes group after group of G codewords ---------------------------------------------------------------
 // llrs [batch][N] i8, output [batch][NP/8] MSB first, iters [batch], success [batch]; `group` = index of the group of G frames.

@@ -17,6 +17,7 @@ struct HipBackend {
     using V = uint32_t;
     char *lds;
 
+    static BS_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
     static BS_FN V c(uint32_t x) { return x; }
     BS_FN V lane() const { return threadIdx.x & 63u; }
     template <int TT> static BS_FN V bitop3(V a, V b, V cc) { return (V)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)cc, TT); }
@@ -50,13 +51,18 @@ struct HipBackend {
     BS_FN V plane_of(uint64_t m) const { return ((m >> (threadIdx.x & 63u)) & 1ull) ? 0xFFFFFFFFu : 0u; }
 };
 
+// waves per SIMD the kernel is compiled for: the rate-1/2 and rate-2/3 codes hold a group of codewords in <= 256 registers; the
+// rate-4/5 codes' state (39 edges: ~250 planes before any temporary) needs the whole file of one wave per SIMD
+template <int CODE> constexpr int waves_per_simd() { return (CODE == TM1280 || CODE == TM5120) ? 1 : 2; }
+
 template <int CODE>
-__global__ void __launch_bounds__(64, 2)         // two waves per SIMD: at most 256 registers
+__global__ void __launch_bounds__(64, waves_per_simd<CODE>())
 decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters,
                     uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t ngroups)
 {
     __shared__ __attribute__((aligned(16))) char lds[Geo<CODE>::LDS_BYTES];
     HipBackend b{lds};
+    init_kernel<CODE, HipBackend>(b);
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g);
 }
 
@@ -81,7 +87,11 @@ hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *out
                                       uint32_t maxiters, hipStream_t stream)
 {
     switch (code) {
+        case TM1280: return bs::launch<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM1536: return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
         case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM5120: return bs::launch<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM6144: return bs::launch<TM6144>(llrs, output, iters, success, batch, maxiters, stream);
         case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
         default: return hipErrorInvalidConfiguration;
     }

@@ -3,7 +3,7 @@
 // cross-lane / LDS / memory operations are plain loops.  Test infrastructure (tests/test_bitslice_emu.py compares its
 // results with the oracle on the CPU, so the formulation -- layout, lane permutations, plane arithmetic, compressed row
 // state -- is validated without a GPU); it is not part of the product and nothing in labrador_ldpc_amd/ links it.
-//   g++ -O2 -std=c++20 -shared -fPIC -Ilabrador_ldpc_amd/csrc tests/c/bitslice_emu.cpp -o build/libbitslice_emu.so
+//   g++ -O1 -std=c++20 -shared -fPIC -DEMU_CODE=TM8192 -Ilabrador_ldpc_amd/csrc tests/c/bitslice_emu.cpp -o build/libbitslice_emu_TM8192.so
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -25,6 +25,7 @@ struct EmuBackend {
     template <class F> static V map1(const V &a, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i]); return r; }
     template <class F> static V map2(const V &a, const V &b, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i], b.l[i]); return r; }
 
+    static void fence() {}
     static V c(uint32_t x) { V r; for (auto &e : r.l) e = x; return r; }
     V lane() const { V r; for (int i = 0; i < 64; ++i) r.l[i] = (uint32_t)i; return r; }
     template <int TT> static V bitop3(const V &a, const V &b, const V &cc)
@@ -77,6 +78,7 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
     const size_t groups = (batch + GEO::G - 1) / GEO::G;
     for (size_t g = 0; g < groups; ++g) {
         EmuBackend b(GEO::LDS_BYTES);
+        ldpc::bs::init_kernel<CODE, EmuBackend>(b);
         ldpc::bs::decode_group<CODE, EmuBackend>(b, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
     }
     return 0;
@@ -84,27 +86,13 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
 
 }  // namespace
 
-extern "C" int bs_emu_decode(int code, const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+// One code per shared object (-DEMU_CODE=TM8192 ...): the six instantiations compile in parallel (tests/test_bitslice_emu.py).
+#ifndef EMU_CODE
+#error "compile with -DEMU_CODE=<TM1280|TM1536|TM2048|TM5120|TM6144|TM8192>"
+#endif
+extern "C" int bs_emu_decode(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
 {
-    switch (code) {
-        case ldpc::TM1280: return run<ldpc::TM1280>(llrs, out, iters, ok, batch, maxiters);
-        case ldpc::TM1536: return run<ldpc::TM1536>(llrs, out, iters, ok, batch, maxiters);
-        case ldpc::TM2048: return run<ldpc::TM2048>(llrs, out, iters, ok, batch, maxiters);
-        case ldpc::TM5120: return run<ldpc::TM5120>(llrs, out, iters, ok, batch, maxiters);
-        case ldpc::TM6144: return run<ldpc::TM6144>(llrs, out, iters, ok, batch, maxiters);
-        case ldpc::TM8192: return run<ldpc::TM8192>(llrs, out, iters, ok, batch, maxiters);
-        default: return -1;
-    }
+    return run<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
 }
-extern "C" int bs_emu_group(int code)
-{
-    switch (code) {
-        case ldpc::TM1280: return ldpc::bs::Geo<ldpc::TM1280>::G;
-        case ldpc::TM1536: return ldpc::bs::Geo<ldpc::TM1536>::G;
-        case ldpc::TM2048: return ldpc::bs::Geo<ldpc::TM2048>::G;
-        case ldpc::TM5120: return ldpc::bs::Geo<ldpc::TM5120>::G;
-        case ldpc::TM6144: return ldpc::bs::Geo<ldpc::TM6144>::G;
-        case ldpc::TM8192: return ldpc::bs::Geo<ldpc::TM8192>::G;
-        default: return 0;
-    }
-}
+extern "C" int bs_emu_group(void) { return ldpc::bs::Geo<ldpc::EMU_CODE>::G; }
+extern "C" int bs_emu_code(void) { return ldpc::EMU_CODE; }

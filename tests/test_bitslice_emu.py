@@ -22,23 +22,34 @@ TM = ["TM1280", "TM1536", "TM2048", "TM5120", "TM6144", "TM8192"]
 
 @pytest.fixture(scope="module")
 def emu():
-    lib = os.path.join(ROOT, "build", "libbitslice_emu.so")
+    """decode(code, llrs, maxiters) through the emulated kernel; one shared object per code, the stale ones rebuilt in parallel
+    (fully unrolled 64-lane code: ~1 minute each at -O1)."""
     src = [os.path.join(ROOT, "tests", "c", "bitslice_emu.cpp"), os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "decode_ms_bitslice.hpp"),
            os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "codes.hpp")]
-    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in src):
-        os.makedirs(os.path.dirname(lib), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++20", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "labrador_ldpc_amd", "csrc"), src[0], "-o", lib])
-    L = ctypes.CDLL(lib)
-    L.bs_emu_decode.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    libs, jobs = {}, []
+    for name in TM:
+        lib = os.path.join(ROOT, "build", f"libbitslice_emu_{name}.so")
+        libs[name] = lib
+        if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in src):
+            jobs.append(subprocess.Popen(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", f"-DEMU_CODE={name}",
+                                          "-I" + os.path.join(ROOT, "labrador_ldpc_amd", "csrc"), src[0], "-o", lib]))
+    assert all(j.wait() == 0 for j in jobs)
+    loaded = {}
+    for name, lib in libs.items():
+        L = ctypes.CDLL(lib)
+        L.bs_emu_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        assert L.bs_emu_code() == oracle.CODES.index(name)
+        loaded[oracle.CODES.index(name)] = L
 
     def decode(code, llrs, maxiters):
         llrs = np.ascontiguousarray(llrs, dtype=np.int8)
         B = llrs.shape[0]
         out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
         it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
-        assert L.bs_emu_decode(code, llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
+        assert loaded[code].bs_emu_decode(llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
         return out, it, ok
-    decode.group = lambda code: L.bs_emu_group(code)
+    decode.group = lambda code: loaded[code].bs_emu_group()
     return decode
 
 

@@ -15,7 +15,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BS = 64                                                       # `variant` of the bit-sliced kernel
-CODES = [LDPCCode.TM2048, LDPCCode.TM8192]
+CODES = [LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048, LDPCCode.TM5120, LDPCCode.TM6144, LDPCCode.TM8192]
 
 
 def _same(code, llrs, maxiters):
@@ -29,7 +29,8 @@ def _same(code, llrs, maxiters):
 @pytest.mark.parametrize("code", CODES)
 def test_bitsliced_kernel_equals_the_oracle(code):
     rng = np.random.default_rng(500 + int(code))
-    for ebn0, scale, lim, frames in ((2.0, 8.0, 31, 257), (1.0, 30.0, 127, 33), (4.5, 16.0, 127, 64), (2.5, 8.0, 31, 1)):
+    hi = 1.5 if code.k() * 5 == code.n() * 4 else 0.0                 # the rate-4/5 codes converge 1.5 dB later
+    for ebn0, scale, lim, frames in ((2.0 + hi, 8.0, 31, 257), (1.0, 30.0, 127, 33), (4.5 + hi, 16.0, 127, 64), (2.5 + hi, 8.0, 31, 1)):
         llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, np.int8, scale=scale, lim=lim)
         for maxiters in (25, 3, 0, 60):
             _same(code, llrs, maxiters)
@@ -64,8 +65,9 @@ def test_bitsliced_kernel_equals_the_default_i8_kernel_on_a_large_batch(code):
     pool = np.zeros((16, code.n() // 8), np.uint8)
     for i in range(16):
         code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
-    frames = 100003                                             # odd: the last wave of TM2048 holds three codewords
-    sigma = float(np.sqrt(1.0 / (2.0 * 0.5 * 10.0 ** 0.2)))
+    ebn0 = 3.5 if code.k() * 5 == code.n() * 4 else (2.5 if code.k() * 3 == code.n() * 2 else 2.0)
+    sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (ebn0 / 10.0))))
+    frames = 100003 if code.n() >= 5120 else 400003            # odd: the last wave is part-filled
     llrs = code.awgn_frames(torch.from_numpy(pool).to(dev), frames, sigma, seed=99, dtype="i8")
     a = code.decode_ms_batch(llrs, 25)
     b = code.decode_ms_batch(llrs, 25, variant=BS)

@@ -6,13 +6,15 @@ import numpy as np, torch
 from labrador_ldpc_amd import LDPCCode
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 dev = torch.device("cuda", 0)
-for code, ebn0 in ((LDPCCode.TM8192, 2.0), (LDPCCode.TM2048, 2.0), (LDPCCode.TM2048, 2.5)):
+CASES = ((LDPCCode.TM8192, 2.0), (LDPCCode.TM2048, 2.0), (LDPCCode.TM2048, 2.5), (LDPCCode.TM6144, 3.0), (LDPCCode.TM1536, 3.0),
+         (LDPCCode.TM5120, 4.0), (LDPCCode.TM5120, 2.0), (LDPCCode.TM1280, 4.0))
+for code, ebn0 in CASES:
     rng = np.random.default_rng(1)
     pool = np.zeros((64, code.n() // 8), np.uint8)
     for i in range(64):
         code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
-    sigma = float(np.sqrt(1.0 / (2.0 * 0.5 * 10.0 ** (ebn0 / 10.0))))
-    fr = frames if code == LDPCCode.TM8192 else frames * 4
+    sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (ebn0 / 10.0))))
+    fr = frames * 8192 // code.n()
     llrs8 = code.awgn_frames(torch.from_numpy(pool).to(dev), fr, sigma, seed=5, dtype="i8")
     llrs32 = code.awgn_frames(torch.from_numpy(pool).to(dev), fr, sigma, seed=5, dtype="f32")
     res = {}
