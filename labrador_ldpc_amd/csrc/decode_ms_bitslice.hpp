@@ -107,10 +107,28 @@ struct Geo {
     // ordinal of block b among the exchanged (pi_k) blocks
     static constexpr int exch_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += local(i) ? 0 : 1; return s; }
     static constexpr int NX = exch_of(NB);
-    // LDS words: LLR planes [NTX][8][64], a 2048-byte staging slab, hard-decision words [NCOLS][64], and the lane permutations of
-    // the exchanged blocks [NX][2 directions][64] (source lane address | rotate amount << 8; constant for the kernel's lifetime)
-    static constexpr int LDS_LLR = 0, LDS_STAGE = NTX * 8 * 64 * 4, LDS_HARD = LDS_STAGE + 2048, LDS_PERM = LDS_HARD + NCOLS * 64 * 4,
-                         LDS_BYTES = LDS_PERM + NX * 2 * 64 * 4;
+    // The rate-4/5 codes keep their LLR planes in a global workspace (one slot per resident wave, re-read from L2 / MALL in every
+    // iteration, 20 KB per wave): in LDS they alone would take the 160 KB of a CU at two waves per SIMD.
+    static constexpr bool LLR_GLOBAL = P.n_blocks > 30;
+    static constexpr int LLR_WORDS = NTX * 8 * 64;                 // words of LLR planes per wave
+    // Register diet of the rate-4/5 codes (39 edges: 218 planes of state before any temporary, against 256 registers at two waves
+    // per SIMD): the hard decisions and the whole state of block row 0 -- three edges per iteration -- live in LDS, the lane
+    // permutations are 16-bit entries.
+    static constexpr bool HARD_LDS = LLR_GLOBAL, ROW0_LDS = LLR_GLOBAL, PERM16 = LLR_GLOBAL;
+    // ... and every state update and every use of the old row state is pinned to its place in the program (Decoder::pin): without
+    // that the instruction selector's data-flow order keeps ~500 values live on these codes.  The smaller codes fit their
+    // registers without the pins and run 6 % faster with the freedom (TM8192 16.9 against 15.9 M codewords/s).
+    static constexpr int PINNED = LLR_GLOBAL ? 2 : (P.n_blocks > 20 ? 1 : 0);       // 2: everything; 1: the state updates only (rate 2/3)
+    static constexpr int ROW_OLD = 15 + ARG, ROW_NEW = 18 + ARG;               // planes of a row's old / running state
+    // LDS: lane permutations of the exchanged blocks [NX][2 directions][64] (source lane address | rotate amount << 8; constant for
+    // the kernel's lifetime), hard-decision words [NCOLS][64], row 0's state [ROW_OLD + ROW_NEW][64] (if ROW0_LDS), LLR planes
+    // [NTX][8][64] (unless in the global workspace), a 2048-byte staging slab for the LLR transposition (aliases row 0's state,
+    // which is initialised after the LLRs are in place)
+    static constexpr int LDS_PERM = 0, LDS_HARD = LDS_PERM + NX * 2 * 64 * (PERM16 ? 2 : 4), LDS_ROW0 = LDS_HARD + NCOLS * 256,
+                         LDS_LLR = LDS_ROW0 + (ROW0_LDS ? (ROW_OLD + ROW_NEW) * 256 : 0),
+                         LDS_STAGE = ROW0_LDS ? LDS_ROW0 : LDS_LLR + (LLR_GLOBAL ? 0 : LLR_WORDS * 4),
+                         LDS_BYTES = ROW0_LDS ? LDS_LLR + (LLR_GLOBAL ? 0 : LLR_WORDS * 4) : LDS_STAGE + 2048;
+    static_assert(!ROW0_LDS || (ROW_OLD + ROW_NEW) * 256 >= 2048);
 };
 
 // ---- arithmetic on bit planes -------------------------------------------------------------------------------------------
@@ -184,7 +202,7 @@ struct Decoder {
         cwbase = B::and_(lane, B::c(~(W - 1) & 63));
     }
 
-    BS_FN void reset_state()
+    BS_FN void reset_state(B &b)
     {
         // decoder.rs:374: the working area is zeroed, so before iteration 0 min1 = min2 = 0, every v = 0, every sign product +
         sfor<0, NROWS>([&](auto R_) {
@@ -192,9 +210,14 @@ struct Decoder {
             sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
             S[r] = B::c(0);
             sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
+            spill_old<r>(b);
         });
         sfor<0, NB>([&](auto E_) { constexpr int e = decltype(E_)::value; sv[e] = B::c(0); nz[e] = B::c(0); });
-        sfor<0, NCOLS>([&](auto C_) { hard[decltype(C_)::value] = B::c(0); });
+        sfor<0, NCOLS>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            if constexpr (GEO::HARD_LDS) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), B::c(0));
+            else hard[c] = B::c(0);
+        });
     }
 
     // "this edge holds the row's min1": arg[r] == slot
@@ -230,9 +253,13 @@ struct Decoder {
 
     // u of edge E at CHECK alignment: sign su, magnitude mg[7]  (decoder.rs:391-405 from the compressed row state)
     template <int E>
-    BS_FN void edge_u(V &su, V (&mg)[7]) const
+    BS_FN void edge_u(V &su, V (&mg)[7])
     {
         constexpr int r = GEO::P.blk[E].row, slot = GEO::slot_of(E);
+        // (everything below depends on the OLD row state only, which exists from the top of the iteration: without the pins the
+        // instruction selector computes every edge's u there and keeps it)
+        sfor<0, ARG>([&](auto K_) { pin(arg[r][decltype(K_)::value]); });
+        pin(S[r]);
         const V sel = is_arg<r, slot>();
         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = op3<TT_MUX>(sel, m2[r][k], m1[r][k]); });
         su = B::xor_(S[r], sv[E]);
@@ -272,6 +299,59 @@ struct Decoder {
         amt = B::add(phi, over);                                                  // rotr by phi + wrap
     }
 
+    static BS_FN void pin(V &x) { if constexpr (GEO::PINNED >= 2) B::pin(x); }
+    static BS_FN void pin_update(V &x) { if constexpr (GEO::PINNED >= 1) B::pin(x); }
+
+    template <int IDX> BS_FN V perm_entry(B &b) const
+    {
+        if constexpr (GEO::PERM16) return b.lds_read_u16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)));
+        else return b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + IDX * 256)));
+    }
+    template <int IDX> BS_FN void put_perm_entry(B &b, V w) const
+    {
+        if constexpr (GEO::PERM16) b.lds_write16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)), w);
+        else b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + IDX * 256)), w);
+    }
+
+    // ---- a row whose state lives in LDS (row 0 of the rate-4/5 codes): the member arrays are temporaries, filled before a use
+    // and spilled after a change, so they hold registers only around the row's three edges ----
+    template <int R> static constexpr bool in_lds() { return GEO::ROW0_LDS && R == 0; }
+    BS_FN V row_addr(int plane) const { return B::add(B::shl(lane, 2), B::c(GEO::LDS_ROW0 + plane * 256)); }
+    template <int R> BS_FN void fill_old(B &b)
+    {
+        if constexpr (in_lds<R>()) {
+            sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[R][k] = b.lds_read32(row_addr(k)); m2[R][k] = b.lds_read32(row_addr(7 + k)); });
+            S[R] = b.lds_read32(row_addr(14));
+            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[R][k] = b.lds_read32(row_addr(15 + k)); });
+        }
+    }
+    template <int R> BS_FN void spill_old(B &b)
+    {
+        if constexpr (in_lds<R>()) {
+            sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(k), m1[R][k]); b.lds_write32(row_addr(7 + k), m2[R][k]); });
+            b.lds_write32(row_addr(14), S[R]);
+            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(15 + k), arg[R][k]); });
+        }
+    }
+    template <int R> BS_FN void fill_new(B &b)
+    {
+        if constexpr (in_lds<R>()) {
+            constexpr int o = GEO::ROW_OLD;
+            sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[R][k] = b.lds_read32(row_addr(o + k)); W2[R][k] = b.lds_read32(row_addr(o + 8 + k)); });
+            Sn[R] = b.lds_read32(row_addr(o + 16)); Pn[R] = b.lds_read32(row_addr(o + 17));
+            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; argn[R][k] = b.lds_read32(row_addr(o + 18 + k)); });
+        }
+    }
+    template <int R> BS_FN void spill_new(B &b)
+    {
+        if constexpr (in_lds<R>()) {
+            constexpr int o = GEO::ROW_OLD;
+            sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(o + k), W1[R][k]); b.lds_write32(row_addr(o + 8 + k), W2[R][k]); });
+            b.lds_write32(row_addr(o + 16), Sn[R]); b.lds_write32(row_addr(o + 17), Pn[R]);
+            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(o + 18 + k), argn[R][k]); });
+        }
+    }
+
     // The permutations depend on the lane only: computed once per kernel into LDS.  ds_bpermute_b32 reads bits 7:2 of its address
     // and v_alignbit_b32 bits 4:0 of its shift, so one word carries both: address | amount << 8.
     BS_FN void init_perm_tables(B &b) const
@@ -281,16 +361,16 @@ struct Decoder {
             if constexpr (!GEO::local(e)) {
                 V addr, amt;
                 perm_c2v<GEO::P.blk[e].val>(addr, amt);
-                b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 0) * 256)), B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
+                put_perm_entry<GEO::exch_of(e) * 2 + 0>(b, B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
                 perm_v2c<GEO::P.blk[e].val>(addr, amt);
-                b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 1) * 256)), B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
+                put_perm_entry<GEO::exch_of(e) * 2 + 1>(b, B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
             }
         });
     }
 
     // ---- one iteration (decoder.rs:380-450), block column by block column -------------------------------------------
     // `frozen`: all ones in the lanes of codewords that are finished (their hard decisions stay as they are)
-    BS_FN V iteration(B &b, V frozen)
+    BS_FN V iteration(B &b, V frozen, const uint32_t *ws)
     {
         sfor<0, NROWS>([&](auto R_) {
             constexpr int r = decltype(R_)::value;
@@ -298,6 +378,7 @@ struct Decoder {
             sfor<1, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = B::c(0xFFFFFFFFu); W2[r][k] = B::c(0xFFFFFFFFu); });
             Sn[r] = B::c(0); Pn[r] = B::c(0);
             sfor<0, ARG>([&](auto K_) { argn[r][decltype(K_)::value] = B::c(0); });
+            spill_new<r>(b);
         });
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
@@ -305,7 +386,13 @@ struct Decoder {
             // ---- variable side: marginal of block column c (decoder.rs:382-383, :408) ----
             V va[8];
             if constexpr (c < NTX) {
-                sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; va[k] = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256))); });
+                V at = B::shl(lane, 2);
+                pin(at);                              // (the loads of this column start here, not at the top of the iteration)
+                sfor<0, 8>([&](auto K_) {
+                    constexpr int k = decltype(K_)::value;
+                    if constexpr (GEO::LLR_GLOBAL) va[k] = b.gload32(ws, B::add(at, B::c((c * 8 + k) * 256)), B::c(0xFFFFFFFFu));
+                    else va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (c * 8 + k) * 256)));
+                });
             } else {
                 sfor<0, 8>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
             }
@@ -313,18 +400,23 @@ struct Decoder {
                 constexpr int e = decltype(E_)::value;
                 if constexpr (GEO::P.blk[e].col == c) {
                     V su, mg[7];
+                    fill_old<GEO::P.blk[e].row>(b);
                     edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
-                        const V addr = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 0) * 256)));
+                        const V addr = perm_entry<GEO::exch_of(e) * 2 + 0>(b);
                         const V amt = B::shr(addr, 8);
                         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
                         su = B::rotr(b.bperm(addr, su), amt);
                     }
                     A::template sat_addsub<false>(va, su, mg);
+                    sfor<0, 8>([&](auto K_) { pin(va[decltype(K_)::value]); });
                     B::fence();
                 }
             });
-            hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
+            if constexpr (GEO::HARD_LDS) {               // read-modify-write, branch-free (an EXEC-masked store splits the loop body into
+                const V at = B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256));      // blocks and wrecks the register allocation)
+                b.lds_write32(at, op3<TT_MUX>(frozen, b.lds_read32(at), va[7]));
+            } else hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
             // ---- check side of the same edges (decoder.rs:419-447) ----
             sfor<0, NB>([&](auto E_) {
                 constexpr int e = decltype(E_)::value;
@@ -332,14 +424,15 @@ struct Decoder {
                     constexpr int r = GEO::P.blk[e].row, slot = GEO::slot_of(e);
                     V nv[8];
                     if constexpr (!GEO::local(e)) {
-                        const V addr = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + (GEO::exch_of(e) * 2 + 1) * 256)));
+                        const V addr = perm_entry<GEO::exch_of(e) * 2 + 1>(b);
                         const V amt = B::shr(addr, 8);
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
                     } else {
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
                     }
-                    Pn[r] = B::xor_(Pn[r], nv[7]);                                   // parity of the marginals' hard bits (:445-447)
+                    const V pbit = nv[7];                                            // hard bit of the marginal (:445-447)
                     V su, mg[7];
+                    fill_old<r>(b);                                                  // (an LDS row: its old state is dead again after edge_u)
                     edge_u<e>(su, mg);
                     A::template sat_addsub<true>(nv, su, mg);                        // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
@@ -353,6 +446,8 @@ struct Decoder {
                     key[0] = op3<TT_KEY0>(vs, all1, key[7]);
                     sv[e] = vs;
                     nz[e] = op3<TT_OR3>(op3<TT_OR3>(key[1], key[2], key[3]), op3<TT_OR3>(key[4], key[5], key[6]), B::or_(key[7], vs));
+                    fill_new<r>(b);                                                  // (an LDS row: filled only now, when nv's temporaries are dead)
+                    Pn[r] = B::xor_(Pn[r], pbit);                                    // parity of the marginals' hard bits
                     Sn[r] = B::xor_(Sn[r], vs);                                      // product of the signs (:438-441)
                     // two running minima (:430-434)
                     const V lt1 = A::less_than(key, W1[r]);
@@ -367,6 +462,14 @@ struct Decoder {
                         constexpr int k = decltype(K_)::value;
                         argn[r][k] = ((slot >> k) & 1) ? B::or_(argn[r][k], lt1) : B::andn(argn[r][k], lt1);
                     });
+                    // The instruction selector orders a basic block by its data flow alone and would compute values whose next use is
+                    // an iteration away (the new v's zero-ness, the row minima) at the END of the block, holding their operands -- seven
+                    // key planes per edge -- in registers until then: 500 live values on the rate-4/5 codes.  An opaque use pins each
+                    // update where it is written.
+                    pin_update(sv[e]); pin_update(nz[e]); pin_update(Sn[r]); pin_update(Pn[r]);
+                    sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_update(W1[r][k]); pin_update(W2[r][k]); });
+                    sfor<0, ARG>([&](auto K_) { pin_update(argn[r][decltype(K_)::value]); });
+                    spill_new<r>(b);
                     B::fence();
                 }
             });
@@ -383,11 +486,13 @@ struct Decoder {
                     c = B::and_(key[k + 1], c);
                 });
             };
+            fill_new<r>(b);
             to_mag(W1[r], m1[r]);
             to_mag(W2[r], m2[r]);
             S[r] = Sn[r];
             sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[r][k] = argn[r][k]; });
             fail = B::or_(fail, Pn[r]);
+            spill_old<r>(b);
         });
         return fail;                                                                  // non-zero bits = unsatisfied checks (:453)
     }
@@ -407,14 +512,13 @@ BS_FN void init_kernel(B &b)
 // (Lane offsets are relative to the group's first frame, so they fit 32 bits whatever the batch.)
 template <int CODE, class B>
 BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint32_t *iters_all, uint8_t *success_all, uint32_t batch,
-                        uint32_t maxiters, uint32_t group)
+                        uint32_t maxiters, uint32_t group, uint32_t *ws = nullptr)
 {
     using GEO = Geo<CODE>;
     using V = typename B::V;
     constexpr int M = GEO::M, N = GEO::N, L = GEO::L, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS, Q = GEO::Q;
     Decoder<CODE, B> d;
     d.init_lane(b);
-    d.reset_state();
     const V lane = d.lane;
     const V cw = B::shr(lane, ilog2c(W));                                    // codeword of the lane inside the group (0 for W = 64)
     const V lw = B::and_(lane, B::c(W - 1));                                 // lane inside the codeword
@@ -463,16 +567,19 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
         stage(IC<1>{}, 0x55555555u);
         sfor<0, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);
+            if constexpr (GEO::LLR_GLOBAL) b.gstore32(ws, B::add(B::shl(lane, 2), B::c((c * 8 + k) * 256)), X[k], B::c(0xFFFFFFFFu));
+            else b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);
         });
     });
+
+    d.reset_state(b);                  // (after the LLRs: row 0's LDS state aliases the staging slab)
 
     // ---- iterations (decoder.rs:380-464): the codewords of the wave run in lockstep, a finished one is frozen ----
     uint64_t frozen_mask = ~valid_mask;
     V iters_v = B::c(maxiters), ok_v = B::c(0);
     for (uint32_t it = 0; it < maxiters && frozen_mask != ~0ull; ++it) {
         const V frozen = b.plane_of(frozen_mask);
-        const V fail = d.iteration(b, frozen);
+        const V fail = d.iteration(b, frozen, ws);
         const uint64_t unsat_lanes = b.ballot(fail);
         uint64_t unsat = 0;
         if constexpr (W == 64) unsat = unsat_lanes ? ~0ull : 0ull;
@@ -489,10 +596,11 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     }
 
     // ---- hard decisions, MSB first (decoder.rs:455-461 / :467-473): plane -> LDS -> one dword of 32 consecutive bits per lane ----
-    sfor<0, NCOLS>([&](auto C_) {
-        constexpr int c = decltype(C_)::value;
-        b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), d.hard[c]);
-    });
+    if constexpr (!GEO::HARD_LDS)
+        sfor<0, NCOLS>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), d.hard[c]);
+        });
     const V b0 = B::shl(d.ll, 5 - ilog2c(L));                                 // first bit of this lane's 32 indices: 32 ll / L
     const V qbase = B::shl(B::add(d.cwbase, B::shl(d.q, ilog2c(L))), 2);     // byte offset of the quarter's first lane
     sfor<0, NCOLS>([&](auto C_) {

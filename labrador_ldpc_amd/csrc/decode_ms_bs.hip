@@ -6,6 +6,7 @@
 // makes room for the next group at once).  LDS per workgroup: the LLRs as bit planes (n bytes per codeword, the size of
 // the raw LLRs), a 2 KB staging slab, one word per lane and block column for the hard decisions.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 
 #include "decode_ms_bitslice.hpp"
@@ -18,6 +19,7 @@ struct HipBackend {
     char *lds;
 
     static BS_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
+    static BS_FN void pin(V &x) { asm volatile("" : "+v"(x)); }          // the value exists in a register HERE (see the iteration)
     static BS_FN V c(uint32_t x) { return x; }
     BS_FN V lane() const { return threadIdx.x & 63u; }
     template <int TT> static BS_FN V bitop3(V a, V b, V cc) { return (V)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)cc, TT); }
@@ -41,6 +43,9 @@ struct HipBackend {
     BS_FN V lds_read32(V addr) const { return *reinterpret_cast<const uint32_t *>(lds + addr); }
     BS_FN void lds_write32(V addr, V v) { *reinterpret_cast<uint32_t *>(lds + addr) = v; }
     BS_FN V lds_read_u8(V addr) const { return *reinterpret_cast<const uint8_t *>(lds + addr); }
+    BS_FN V lds_read_u16(V addr) const { return *reinterpret_cast<const uint16_t *>(lds + addr); }
+    BS_FN void lds_write16(V addr, V v) { *reinterpret_cast<uint16_t *>(lds + addr) = (uint16_t)v; }
+    BS_FN void lds_write32_if(V addr, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(lds + addr) = v; }
     static BS_FN V gload32(const void *p, V off, V pred)
     {
         return pred ? *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off) : 0u;
@@ -53,17 +58,18 @@ struct HipBackend {
 
 // waves per SIMD the kernel is compiled for: the rate-1/2 and rate-2/3 codes hold a group of codewords in <= 256 registers; the
 // rate-4/5 codes' state (39 edges: ~250 planes before any temporary) needs the whole file of one wave per SIMD
-template <int CODE> constexpr int waves_per_simd() { return (CODE == TM1280 || CODE == TM5120) ? 1 : 2; }
+template <int CODE> constexpr int waves_per_simd() { return 2; }
 
 template <int CODE>
 __global__ void __launch_bounds__(64, waves_per_simd<CODE>())
 decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters,
-                    uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t ngroups)
+                    uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t ngroups, uint32_t *__restrict__ workspace)
 {
     __shared__ __attribute__((aligned(16))) char lds[Geo<CODE>::LDS_BYTES];
     HipBackend b{lds};
     init_kernel<CODE, HipBackend>(b);
-    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g);
+    uint32_t *ws = Geo<CODE>::LLR_GLOBAL ? workspace + (size_t)blockIdx.x * Geo<CODE>::LLR_WORDS : nullptr;      // this wave's slot
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g, ws);
 }
 
 template <int CODE>
@@ -73,10 +79,34 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
     if (batch == 0) return hipSuccess;
     if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const size_t groups = (batch + G - 1) / G;
-    const size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
+    size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
+    uint32_t *ws = nullptr;
+    if constexpr (Geo<CODE>::LLR_GLOBAL) {
+        // persistent waves, one workspace slot each: the grid is the resident set (the groups are dealt with a fixed stride;
+        // a wave decodes dozens of them, so the data-dependent iteration counts average out)
+        static std::atomic<int> cached[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int resident = cached[dev].load(std::memory_order_relaxed);
+        if (resident == 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_bs_kernel<CODE>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            resident = per_cu * cus;
+            cached[dev].store(resident, std::memory_order_relaxed);
+        }
+        if (grid > (size_t)resident) grid = (size_t)resident;
+        const hipError_t e = hipMallocAsync((void **)&ws, grid * Geo<CODE>::LLR_WORDS * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((decode_ms_bs_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
-                       (uint32_t)groups);
-    return hipGetLastError();
+                       (uint32_t)groups, ws);
+    hipError_t e = hipGetLastError();
+    if (ws != nullptr) {
+        const hipError_t e2 = hipFreeAsync(ws, stream);
+        if (e == hipSuccess) e = e2;
+    }
+    return e;
 }
 
 }  // namespace bs

@@ -16,10 +16,27 @@ namespace ldpc {
     X(TM6144, int8_t, 1, 2) \
     X(TM8192, int8_t, 2)
 
-// the bit-sliced kernel (decode_ms_bs.hip): `variant` 64
+// The bit-sliced kernel (decode_ms_bs.hip, decode_ms_bitslice.hpp): `variant` 64, and the DEFAULT for the TM codes from
+// bitslice_min_batch() frames up -- one wave decodes a group of 64 / (M/32) codewords on its own, so it needs ~2048 groups in flight
+// to fill the chip and takes ~3x as long per codeword as a whole workgroup of the f32-pipe kernels: below ~1024 groups those are
+// faster (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
                                       uint32_t maxiters, hipStream_t stream);
 constexpr int VARIANT_BITSLICE = 64;
+constexpr size_t bitslice_min_batch(int code)
+{
+    return code >= TM1280 && code <= TM8192 ? (size_t)1024 * (size_t)(64 / (CODES[code].m / 32)) : ~(size_t)0;
+}
+static bool bitslice_default(int code, const int8_t *llrs, size_t batch, hipStream_t stream)
+{
+    if (batch < bitslice_min_batch(code) || (uintptr_t)llrs % 4) return false;
+    if (code == TM1280 || code == TM5120) {        // (these allocate their LLR workspace stream-ordered: not inside a graph capture)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (stream == hipStreamPerThread || (stream != nullptr && (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone)))
+            return false;
+    }
+    return true;
+}
 
 template <>
 hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, uint8_t *output,
@@ -31,6 +48,8 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
         if ((uintptr_t)llrs % 4) return hipErrorInvalidConfiguration;        // (its loads are dwords)
         return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
     }
+    if (variant == 0 && lflags == 0 && bitslice_default(code, llrs, batch, stream))
+        return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
     // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
         if (code == TM8192) return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);

@@ -26,6 +26,7 @@ struct EmuBackend {
     template <class F> static V map2(const V &a, const V &b, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i], b.l[i]); return r; }
 
     static void fence() {}
+    static void pin(V &) {}
     static V c(uint32_t x) { V r; for (auto &e : r.l) e = x; return r; }
     V lane() const { V r; for (int i = 0; i < 64; ++i) r.l[i] = (uint32_t)i; return r; }
     template <int TT> static V bitop3(const V &a, const V &b, const V &cc)
@@ -58,6 +59,9 @@ struct EmuBackend {
     V bperm(const V &addr, const V &x) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = x.l[(addr.l[i] >> 2) & 63]; return r; }
     V lds_read32(const V &addr) const { V r; for (int i = 0; i < 64; ++i) std::memcpy(&r.l[i], &lds.at(addr.l[i]), 4), (void)lds.at(addr.l[i] + 3); return r; }
     void lds_write32(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { (void)lds.at(addr.l[i] + 3); std::memcpy(&lds.at(addr.l[i]), &v.l[i], 4); } }
+    V lds_read_u16(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds.at(addr.l[i]) | (uint32_t)lds.at(addr.l[i] + 1) << 8; return r; }
+    void lds_write16(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { lds.at(addr.l[i]) = (uint8_t)v.l[i]; lds.at(addr.l[i] + 1) = (uint8_t)(v.l[i] >> 8); } }
+    void lds_write32_if(const V &addr, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) { (void)lds.at(addr.l[i] + 3); std::memcpy(&lds.at(addr.l[i]), &v.l[i], 4); } }
     V lds_read_u8(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds.at(addr.l[i]); return r; }
     static V gload32(const void *p, const V &off, const V &pred)
     {
@@ -79,7 +83,8 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
     for (size_t g = 0; g < groups; ++g) {
         EmuBackend b(GEO::LDS_BYTES);
         ldpc::bs::init_kernel<CODE, EmuBackend>(b);
-        ldpc::bs::decode_group<CODE, EmuBackend>(b, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
+        std::vector<uint32_t> ws(GEO::LLR_GLOBAL ? GEO::LLR_WORDS : 1, 0xA5A5A5A5u);      // the wave's slot of the LLR workspace
+        ldpc::bs::decode_group<CODE, EmuBackend>(b, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g, ws.data());
     }
     return 0;
 }

@@ -69,8 +69,12 @@ def test_bitsliced_kernel_equals_the_default_i8_kernel_on_a_large_batch(code):
     sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (ebn0 / 10.0))))
     frames = 100003 if code.n() >= 5120 else 400003            # odd: the last wave is part-filled
     llrs = code.awgn_frames(torch.from_numpy(pool).to(dev), frames, sigma, seed=99, dtype="i8")
-    a = code.decode_ms_batch(llrs, 25)
+    old = 32 if code == LDPCCode.TM8192 else 1                  # the f32-pipe kernels by their explicit variant
+    a = code.decode_ms_batch(llrs, 25, variant=old)
     b = code.decode_ms_batch(llrs, 25, variant=BS)
+    c = code.decode_ms_batch(llrs, 25)                          # the default: bit-sliced from 1024 groups up
     torch.cuda.synchronize()
-    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(a, c))
     assert 0.5 < float(a[2].float().mean()) <= 1.0
+    small = llrs[:777]                                          # below the threshold the default is the f32-pipe kernel: same results
+    assert all(torch.equal(x, y[:777]) for x, y in zip(code.decode_ms_batch(small, 25), a))
