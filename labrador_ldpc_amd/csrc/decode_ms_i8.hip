@@ -18,14 +18,18 @@ namespace ldpc {
 
 // The bit-sliced kernel (decode_ms_bs.hip, decode_ms_bitslice.hpp): `variant` 64, and the DEFAULT for the TM codes from
 // bitslice_min_batch() frames up -- one wave decodes a group of 64 / (M/32) codewords on its own, so it needs ~2048 groups in flight
-// to fill the chip and takes ~3x as long per codeword as a whole workgroup of the f32-pipe kernels: below ~1024 groups those are
-// faster (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
+// to fill the chip and takes ~3x as long per codeword as a whole workgroup of the f32-pipe kernels: small batches are
+// faster on those (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
                                       uint32_t maxiters, hipStream_t stream);
 constexpr int VARIANT_BITSLICE = 64;
+// groups of 64 / (M/32) codewords from which the bit-sliced kernel is faster per call (tools/bs_crossover.py,
+// profiles/r04_kbench/bs_crossover.txt: TM8192 and TM6144 cross at 1024 groups, TM2048 and TM5120 at 2048, TM1536 at 8192, TM1280 --
+// sixteen codewords of a wave in lockstep -- only beyond 16 384)
 constexpr size_t bitslice_min_batch(int code)
 {
-    return code >= TM1280 && code <= TM8192 ? (size_t)1024 * (size_t)(64 / (CODES[code].m / 32)) : ~(size_t)0;
+    constexpr size_t groups[NUM_CODES] = {0, 0, 0, 32768, 8192, 2048, 2048, 1024, 1024};
+    return code >= TM1280 && code <= TM8192 ? groups[code] * (size_t)(64 / (CODES[code].m / 32)) : ~(size_t)0;
 }
 static bool bitslice_default(int code, const int8_t *llrs, size_t batch, hipStream_t stream)
 {
