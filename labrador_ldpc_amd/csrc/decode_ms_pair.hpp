@@ -45,7 +45,7 @@ struct PairGeometry {
     static constexpr int NX = count_exchanged(*CODES[CODE].proto);
     static constexpr int NXC = count_exch_cols(*CODES[CODE].proto);
     static constexpr int OUT_LEN = CODES[CODE].output_len();
-    static constexpr int LDS_BYTES = ((NX + NXC) * M * 4 + 8 + 15) / 16 * 16;
+    static constexpr int LDS_BYTES = ((NX + NXC) * M * 4 + 8 + 15) / 16 * 16 + (LDPC_PAIR_ARRIVE_WAIT ? 16 : 0);     // (+ four arrive counters)
     static_assert(M % 512 == 0 && NT <= 1024, "pair ownership needs M/8 >= 64 lanes per quarter and <= 1024 threads");
 };
 
@@ -102,6 +102,21 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     auto lds2 = [&](int off) LDPC_INLINE -> ldpc_f2 & { return *reinterpret_cast<ldpc_f2 *>(lds + off); };
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 4 * (which & 1)); };
     auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 8); };
+    // LDPC_PAIR_ARRIVE_WAIT: arrive counters (per quarter of the workgroup) behind the flag words; `arrivals` = variable phases so far
+    auto arrive_word = [&](int qtr) LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 16 + 4 * qtr); };
+    uint32_t arrivals = 0;
+    constexpr int WAVES_PER_QUARTER = GEO::NT / 64 / 4;
+    auto arrive = [&]() LDPC_INLINE {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's marginal stores have landed
+        if ((t & 63) == 0) __hip_atomic_fetch_add(&arrive_word(LDPC_PAIR_ARRIVE_WAIT == 2 ? t / (GEO::NT / 4) : 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++arrivals;
+    };
+    auto wait_for = [&](int qtr) LDPC_INLINE {                               // until every wave (of quarter qtr) has arrived `arrivals` times
+        const int want = (int)arrivals * (LDPC_PAIR_ARRIVE_WAIT == 2 ? WAVES_PER_QUARTER : 4 * WAVES_PER_QUARTER);
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arrive_word(LDPC_PAIR_ARRIVE_WAIT == 2 ? qtr : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
     constexpr bool NOCAP_POSSIBLE = LDPC_PAIR_NOCAP && std::is_same_v<T, float>;
 
     // Rotation of block B for this body's quarter JW: phi, and where the even/odd split puts the edges.
@@ -155,6 +170,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         });
 #endif
         if (t < 2) flag_at(t) = 0;
+        if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) { if (t >= 4 && t < 8) arrive_word(t - 4) = 0; arrivals = 0; }
         // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
         // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
         // |LLR| <= nocap_limit (derived from max_iters by the host: nocap_limit_for(), decode_ms_launch.hpp)
@@ -248,10 +264,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         LDPC_SETPRIO(3);
         R xs[IPT][NB];
         int ad[IPT][NB];
+        auto request_marginals = [&]() LDPC_INLINE {
         static_for<0, NB>([&](auto B_) LDPC_INLINE {                                   // (1) request the exchanged marginals
             constexpr int B = decltype(B_)::value;
             constexpr int slot = exch_slot(P, B);
             if constexpr (slot >= 0) {
+                if constexpr (LDPC_PAIR_ARRIVE_WAIT == 2) wait_for(((t / (GEO::NT / 4)) + theta_of(P.blk[B].val)) & 3);      // the quarter this block's marginals were written by
                 constexpr int cs = col_slot(P, P.blk[B].col);
                 constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                 if constexpr (even_c(B)) {
@@ -276,7 +294,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 }
             }
         });
-        __builtin_amdgcn_sched_barrier(0);
+        };
+        auto local_edges = [&]() LDPC_INLINE {
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (2) local edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
                 constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
@@ -286,6 +305,17 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 }
             });
         });
+        };
+        if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) {
+            local_edges();                         // needs the thread's own marginals only: runs while the other waves arrive
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LDPC_PAIR_ARRIVE_WAIT == 1) wait_for(0);
+            request_marginals();
+        } else {
+            request_marginals();
+            __builtin_amdgcn_sched_barrier(0);
+            local_edges();
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
@@ -400,7 +430,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             if constexpr (LDPC_PAIR_PEEL_FIRST != 0) {
                 if (maxiters == 0) { done = true; return; }
                 variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{}, IC<1>{});
-                LDPC_SYNC();
+                if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) arrive(); else LDPC_SYNC();
                 check_phase(0u, CAP_, IC<1>{});
                 collect_claim();
                 it0 = 1;
@@ -419,7 +449,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-                LDPC_SYNC();
+                if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) arrive(); else LDPC_SYNC();
 #ifdef LDPC_DIAG_STAMPS
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif

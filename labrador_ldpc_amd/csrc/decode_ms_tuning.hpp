@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH) || defined(LDPC_DIAG_NOCAP_ONLY)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH) || defined(LDPC_DIAG_NOCAP_ONLY) || defined(LDPC_PAIR_ARRIVE_WAIT)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
@@ -123,6 +123,13 @@
 #endif
 // Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = the default (on: i8/i16 8.0 -> 9.0 in
 // round 1; f32 7.05 -> 6.90 then, 8.33 -> 8.44 with round 3's check phase), 0 / 1 = force.
+// Round 4 experiment (profiles/r04_kbench/arrive_wait.txt): the workgroup barrier between the variable and the
+// check phase as arrive (one LDS atomic per wave) + wait (poll before the first read of an exchanged marginal), with the check
+// phase's local-edge updates in between.  1 = one counter for the workgroup, 2 = one per quarter and each block waits only for the
+// quarter its marginals come from.  Both slower than the barrier: off.
+#ifndef LDPC_PAIR_ARRIVE_WAIT
+#define LDPC_PAIR_ARRIVE_WAIT 0
+#endif
 #ifndef LDPC_PAIR_ODD_B64
 #define LDPC_PAIR_ODD_B64 -1
 #endif
