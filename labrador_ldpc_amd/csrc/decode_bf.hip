@@ -17,6 +17,7 @@
 //  * returned iterations = bit-flipping iterations + erasure iterations (= +0), decoder.rs:289, :300.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 #include "decode_bf.hpp"
 #include "decode_ms_kernel.hpp"      // static_for, pi_dev, prototype helpers
@@ -26,6 +27,7 @@ namespace ldpc {
 namespace {
 
 constexpr int BF_THREADS = 256;
+constexpr int BF_BITSLICE_MIN_GROUPS = 256;
 
 constexpr int punctured_edges_in_row(const Prototype &p, int row, int ntx)
 {
@@ -154,10 +156,21 @@ hipError_t launch(const uint8_t *input, uint8_t *output, uint32_t *iters, uint8_
 
 }  // namespace
 
+// the bit-sliced kernel (decode_bf_bs.hip, decode_bf_bitslice.hpp): TM codes
+hipError_t launch_decode_bf_bitsliced(int code, const uint8_t *input, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                      uint32_t maxiters, hipStream_t stream);
+
 hipError_t launch_decode_bf(int code, const uint8_t *input, uint8_t *output, uint32_t *iters, uint8_t *success,
                             size_t batch, uint32_t maxiters, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
+    // TM codes, from BF_BITSLICE_MIN_GROUPS groups of 64 / (M/32) codewords up: one wave decodes a group on its own with one register
+    // per block column (decode_bf_bitslice.hpp); below that the workgroup-per-codeword kernel here has the shorter latency.
+    // LABRADOR_LDPC_HIP_BF_BYTES=1 forces the byte-per-variable kernel (A/B timing, tests).
+    static const bool force_bytes = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_BF_BYTES"); return e && *e && *e != '0'; }();
+    if (!force_bytes && code >= TM1280 && code <= TM8192 && (uintptr_t)input % 4 == 0 && (uintptr_t)output % 4 == 0 &&
+        batch >= (size_t)BF_BITSLICE_MIN_GROUPS * (size_t)(64 / (CODES[code].m / 32)))
+        return launch_decode_bf_bitsliced(code, input, output, iters, success, batch, maxiters, stream);
     switch (code) {
         case TC128:  return launch<TC128>(input, output, iters, success, batch, maxiters, stream);
         case TC256:  return launch<TC256>(input, output, iters, success, batch, maxiters, stream);

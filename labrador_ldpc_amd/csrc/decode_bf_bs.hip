@@ -1,0 +1,54 @@
+// decode_bf_bs.hip -- gfx950 instantiation of the bit-sliced hard-decision decoder (decode_bf_bitslice.hpp: LDPCCode::decode_bf,
+// /root/reference/src/decoder.rs:243-301, with decode_erasures, :144-223) for the TM codes: one wave per group of 64 / (M/32) codewords.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "decode_bf_bitslice.hpp"
+#include "hip_backend.hpp"
+
+namespace ldpc {
+namespace bs {
+
+template <int CODE>
+__global__ void __launch_bounds__(64, 4)
+decode_bf_bs_kernel(const uint8_t *__restrict__ input, uint8_t *__restrict__ output, uint32_t *__restrict__ iters, uint8_t *__restrict__ success,
+                    uint32_t batch, uint32_t maxiters, uint32_t ngroups)
+{
+    __shared__ __attribute__((aligned(16))) char lds[BfGeo<CODE>::LDS_BYTES];
+    HipBackend b{lds};
+    bf_init_kernel<CODE, HipBackend>(b);
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) bf_decode_group<CODE, HipBackend>(b, input, output, iters, success, batch, maxiters, g);
+}
+
+template <int CODE>
+hipError_t launch_bf(const uint8_t *input, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
+{
+    constexpr int G = Geo<CODE>::G;
+    if (batch == 0) return hipSuccess;
+    if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const size_t groups = (batch + G - 1) / G;
+    // persistent waves: 16 per CU x 256 CUs cover the chip; a decode is a few microseconds, so the groups are dealt with a fixed stride
+    const size_t grid = groups < 16384 ? groups : 16384;
+    hipLaunchKernelGGL((decode_bf_bs_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, input, output, iters, success, (uint32_t)batch, maxiters,
+                       (uint32_t)groups);
+    return hipGetLastError();
+}
+
+}  // namespace bs
+
+// hipErrorInvalidConfiguration for the codes it is not built for (the TC codes).  input and output 4-byte aligned.
+hipError_t launch_decode_bf_bitsliced(int code, const uint8_t *input, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                      uint32_t maxiters, hipStream_t stream)
+{
+    switch (code) {
+        case TM1280: return bs::launch_bf<TM1280>(input, output, iters, success, batch, maxiters, stream);
+        case TM1536: return bs::launch_bf<TM1536>(input, output, iters, success, batch, maxiters, stream);
+        case TM2048: return bs::launch_bf<TM2048>(input, output, iters, success, batch, maxiters, stream);
+        case TM5120: return bs::launch_bf<TM5120>(input, output, iters, success, batch, maxiters, stream);
+        case TM6144: return bs::launch_bf<TM6144>(input, output, iters, success, batch, maxiters, stream);
+        case TM8192: return bs::launch_bf<TM8192>(input, output, iters, success, batch, maxiters, stream);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+
+}  // namespace ldpc

@@ -10,51 +10,11 @@
 #include <cstdint>
 
 #include "decode_ms_bitslice.hpp"
+#include "hip_backend.hpp"
 
 namespace ldpc {
 namespace bs {
 
-struct HipBackend {
-    using V = uint32_t;
-    char *lds;
-
-    static BS_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
-    static BS_FN void pin(V &x) { asm volatile("" : "+v"(x)); }          // the value exists in a register HERE (see the iteration)
-    static BS_FN V c(uint32_t x) { return x; }
-    BS_FN V lane() const { return threadIdx.x & 63u; }
-    template <int TT> static BS_FN V bitop3(V a, V b, V cc) { return (V)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)cc, TT); }
-    static BS_FN V and_(V a, V b) { return a & b; }
-    static BS_FN V or_(V a, V b) { return a | b; }
-    static BS_FN V xor_(V a, V b) { return a ^ b; }
-    static BS_FN V andn(V a, V b) { return a & ~b; }
-    static BS_FN V not_(V a) { return ~a; }
-    static BS_FN V add(V a, V b) { return a + b; }
-    static BS_FN V sub(V a, V b) { return a - b; }
-    static BS_FN V mul_u(V a, uint32_t k) { return a * k; }
-    static BS_FN V shl(V a, int s) { return a << s; }
-    static BS_FN V shr(V a, int s) { return a >> s; }
-    static BS_FN V sar(V a, int s) { return (V)((int32_t)a >> s); }
-    static BS_FN V shr_v(V a, V s) { return a >> (s & 31u); }
-    static BS_FN V bfe(V v, V off, int width) { return __builtin_amdgcn_ubfe(v, off, (uint32_t)width); }
-    static BS_FN V rotr(V x, V amt) { return __builtin_amdgcn_alignbit(x, x, amt); }
-    static BS_FN V less_u(V a, V b) { return a < b ? 0xFFFFFFFFu : 0u; }
-    static BS_FN V eq(V a, V b) { return a == b ? 0xFFFFFFFFu : 0u; }
-    BS_FN V bperm(V addr, V x) const { return (V)__builtin_amdgcn_ds_bpermute((int)addr, (int)x); }
-    BS_FN V lds_read32(V addr) const { return *reinterpret_cast<const uint32_t *>(lds + addr); }
-    BS_FN void lds_write32(V addr, V v) { *reinterpret_cast<uint32_t *>(lds + addr) = v; }
-    BS_FN V lds_read_u8(V addr) const { return *reinterpret_cast<const uint8_t *>(lds + addr); }
-    BS_FN V lds_read_u16(V addr) const { return *reinterpret_cast<const uint16_t *>(lds + addr); }
-    BS_FN void lds_write16(V addr, V v) { *reinterpret_cast<uint16_t *>(lds + addr) = (uint16_t)v; }
-    BS_FN void lds_write32_if(V addr, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(lds + addr) = v; }
-    static BS_FN V gload32(const void *p, V off, V pred)
-    {
-        return pred ? *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off) : 0u;
-    }
-    static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off) = v; }
-    static BS_FN void gstore8(void *p, V off, V v, V pred) { if (pred) static_cast<uint8_t *>(p)[off] = (uint8_t)v; }
-    static BS_FN uint64_t ballot(V x) { return __ballot(x != 0u); }
-    BS_FN V plane_of(uint64_t m) const { return ((m >> (threadIdx.x & 63u)) & 1ull) ? 0xFFFFFFFFu : 0u; }
-};
 
 // waves per SIMD the kernel is compiled for: the rate-1/2 and rate-2/3 codes hold a group of codewords in <= 256 registers; the
 // rate-4/5 codes' state (39 edges: ~250 planes before any temporary) needs the whole file of one wave per SIMD

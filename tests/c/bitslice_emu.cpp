@@ -10,6 +10,7 @@
 
 #define BS_FN inline
 #include "decode_ms_bitslice.hpp"
+#include "decode_bf_bitslice.hpp"
 
 namespace {
 
@@ -51,6 +52,7 @@ struct EmuBackend {
     static V shl(const V &a, int s) { return map1(a, [s](uint32_t x) { return x << s; }); }
     static V shr(const V &a, int s) { return map1(a, [s](uint32_t x) { return x >> s; }); }
     static V sar(const V &a, int s) { return map1(a, [s](uint32_t x) { return (uint32_t)((int32_t)x >> s); }); }
+    static V shl_v(const V &a, const V &s) { return map2(a, s, [](uint32_t x, uint32_t y) { return x << (y & 31); }); }
     static V shr_v(const V &a, const V &s) { return map2(a, s, [](uint32_t x, uint32_t y) { return x >> (y & 31); }); }
     static V bfe(const V &v, const V &off, int width) { return map2(v, off, [width](uint32_t x, uint32_t o) { return (x >> (o & 31)) & ((1u << width) - 1); }); }
     static V rotr(const V &x, const V &amt) { return map2(x, amt, [](uint32_t v, uint32_t a) { a &= 31; return a ? (v >> a) | (v << (32 - a)) : v; }); }
@@ -98,6 +100,17 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
 extern "C" int bs_emu_decode(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
 {
     return run<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+}
+extern "C" int bs_emu_decode_bf(const uint8_t *input, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    using GEO = ldpc::bs::Geo<ldpc::EMU_CODE>;
+    const size_t groups = (batch + GEO::G - 1) / GEO::G;
+    for (size_t g = 0; g < groups; ++g) {
+        EmuBackend b(ldpc::bs::BfGeo<ldpc::EMU_CODE>::LDS_BYTES);
+        ldpc::bs::bf_init_kernel<ldpc::EMU_CODE, EmuBackend>(b);
+        ldpc::bs::bf_decode_group<ldpc::EMU_CODE, EmuBackend>(b, input, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
+    }
+    return 0;
 }
 extern "C" int bs_emu_group(void) { return ldpc::bs::Geo<ldpc::EMU_CODE>::G; }
 extern "C" int bs_emu_code(void) { return ldpc::EMU_CODE; }

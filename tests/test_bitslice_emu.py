@@ -39,6 +39,7 @@ def emu():
     for name, lib in libs.items():
         L = ctypes.CDLL(lib)
         L.bs_emu_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        L.bs_emu_decode_bf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         assert L.bs_emu_code() == oracle.CODES.index(name)
         loaded[oracle.CODES.index(name)] = L
 
@@ -49,7 +50,15 @@ def emu():
         it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
         assert loaded[code].bs_emu_decode(llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
         return out, it, ok
+    def decode_bf(code, hard, maxiters):
+        hard = np.ascontiguousarray(hard, dtype=np.uint8)
+        B = hard.shape[0]
+        out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
+        it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
+        assert loaded[code].bs_emu_decode_bf(hard.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
+        return out, it, ok
     decode.group = lambda code: loaded[code].bs_emu_group()
+    decode.bf = decode_bf
     return decode
 
 
@@ -98,3 +107,33 @@ def test_emulated_kernel_reproduces_the_i8_golden_files(emu):
         for maxiters in (25, 4, 0):
             o, i, k = emu(code, z["llrs"], maxiters)
             assert (o == z[f"output_{maxiters}"]).all() and (i == z[f"iters_{maxiters}"]).all() and (k == z[f"success_{maxiters}"]).all(), (f, maxiters)
+
+
+@pytest.mark.parametrize("name", TM)
+def test_emulated_bit_sliced_decode_bf_equals_the_oracle(emu, name):
+    """csrc/decode_bf_bitslice.hpp (decode_bf + the erasure pre-pass, decoder.rs:144-301) lane by lane against the oracle's restatement:
+    clean codewords, the reference's three-flip scenario (decoder.rs:647-670), random error patterns that converge slowly or fail,
+    part-filled waves, max_iters 0 / 1 / 2 / 20."""
+    code = oracle.CODES.index(name)
+    rng = np.random.default_rng(300 + code)
+    N, K = oracle.n(code), oracle.k(code)
+    B = 2 * emu.group(code) + 3
+    hard = np.zeros((B, N // 8), dtype=np.uint8)
+    for f in range(B):
+        cw = oracle.copy_encode(code, rng.integers(0, 256, K // 8, dtype=np.uint8))
+        nerr = 0 if f == 0 else (3 if f == 1 else int(rng.integers(0, max(2, N // 40))))
+        if f == 1:
+            cw[0] ^= 0xA8
+        else:
+            for pos in rng.choice(N, nerr, replace=False):
+                cw[pos // 8] ^= 1 << (7 - pos % 8)
+        hard[f] = cw
+    seen_ok = False
+    for maxiters in (20, 0, 1, 2):
+        o, i, k = emu.bf(code, hard, maxiters)
+        for f in range(B):
+            ok_c, it_c, out_c = oracle.decode_bf(code, hard[f], maxiters)
+            assert (bool(k[f]), int(i[f])) == (ok_c, it_c), (name, maxiters, f, int(i[f]), it_c)
+            assert (o[f] == out_c).all(), (name, maxiters, f)
+        seen_ok = seen_ok or bool(k.any())
+    assert seen_ok
