@@ -88,6 +88,6 @@ def test_bit_sliced_kernel_on_large_batches(code):
         for f in list(range(0, 40)) + [B - 1, B - 2]:
             ok_c, it_c, out_c = oracle.decode_bf(code, hard[f], maxiters)
             assert (bool(ok[f]), int(it[f])) == (ok_c, it_c) and (out[f] == out_c).all(), (code.name, maxiters, f)
-    assert ok.sum() == 0                                                        # (the last loop ran max_iters = 1: nothing converges at once ...)
+    one = int(ok.sum())                                                         # (max_iters = 1: only the error-free frames succeed ...)
     out, it, ok = code.decode_bf_batch(hard, 20)
-    assert 0 < ok.sum() <= B                                                    # ... and at 20 most frames do
+    assert 0 < one < int(ok.sum()) <= B                                         # ... at 20 most frames do

@@ -22,5 +22,6 @@ pmc TC512_f32  --code TC512  --frames-per-gpu 65536   --ebn0 2.0
 pmc TM2048_f32 --code TM2048 --frames-per-gpu 262144  --ebn0 2.0
 pmc TM5120_i8  --code TM5120 --dtype i8 --frames-per-gpu 131072 --ebn0 4.0
 pmc TM5120_i8_2dB --code TM5120 --dtype i8 --frames-per-gpu 131072 --ebn0 2.0
+pmc TM8192_i8 --code TM8192 --dtype i8 --frames-per-gpu 65536 --ebn0 2.0
 find $O -name "*.csv" | wc -l
 tail -1 $O/trace_bench.log | cut -c1-200

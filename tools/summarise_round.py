@@ -23,7 +23,7 @@ for f in ("bench_default.json", "trace_bench.log"):
 # operating point (bench.py profile_key: "<code>_<dtype>_<Eb/N0>dB_<max_iters>it")
 CONFIGS = {"TM8192_f32": (65536, 8192 * 4 + 1280 + 5, 2.0, 25), "TC512_f32": (65536, 512 * 4 + 64 + 5, 2.0, 25),
            "TM2048_f32": (262144, 2048 * 4 + 320 + 5, 2.0, 25), "TM5120_i8": (131072, 5120 + 704 + 5, 4.0, 25),
-           "TM5120_i8_2dB": (131072, 5120 + 704 + 5, 2.0, 25)}
+           "TM5120_i8_2dB": (131072, 5120 + 704 + 5, 2.0, 25), "TM8192_i8": (65536, 8192 + 1280 + 5, 2.0, 25)}
 traffic, allsum = {}, {}
 for tag, (frames, alg, ebn0, maxit) in CONFIGS.items():
     key = f"{'_'.join(tag.split('_')[:2])}_{ebn0:g}dB_{maxit}it"
