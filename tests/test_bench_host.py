@@ -63,21 +63,29 @@ def test_roofline_of_prints_null_valu_issue_for_an_unprofiled_operating_point(tm
     b = _bench()
     build = "aaaaaaaaaaaaaaaa"
     prof = {"library_build": build,
-            b.profile_key("TM5120", "i8", 4.0, 25): {"frames": 131072, "hbm_bytes_per_launch": 7.7e8, "valu_insts_per_launch": 4.3e9}}
+            b.profile_key("TM2048", "i8", 4.0, 25): {"frames": 131072, "hbm_bytes_per_launch": 3.1e8, "valu_insts_per_launch": 4.3e9},
+            b.profile_key("TM5120", "i8", 4.0, 25): {"frames": 131072, "hbm_bytes_per_launch": 8.5e9, "valu_insts_per_launch": 2.3e9}}
     path = tmp_path / "profiles" / "hbm_traffic.json"
     path.parent.mkdir()
     path.write_text(json.dumps(prof))
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
 
     class Code:
-        def n(self): return 5120
-        def output_len(self): return 704
-        def paritycheck_sum(self): return 19968
-    roof, valu = b.roofline_of(Code(), "TM5120", "i8", 0, 524288, 23.5, 8.4, build, 4.0, 25)
-    assert valu and abs(valu["achieved"] - 4.3e9 * 4 / 23.5e-3 / 1e9) < 1e-6 and roof["traffic"] == 7.7e8 * 4
-    roof, valu = b.roofline_of(Code(), "TM5120", "i8", 0, 524288, 61.2, 25.0, build, 2.0, 25)
-    assert valu is None and "no profile of TM5120_i8_2dB_25it" in roof["valu_issue_note"]
-    assert roof["traffic"] == 7.7e8 * 4 and "TM5120_i8_4dB_25it" in roof["traffic_source"]      # bytes per frame: any operating point
+        def __init__(self, n, out, e): self._n, self._o, self._e = n, out, e
+        def n(self): return self._n
+        def output_len(self): return self._o
+        def paritycheck_sum(self): return self._e
+    tm2048, tm5120 = Code(2048, 320, 7680), Code(5120, 704, 19968)
+    roof, valu = b.roofline_of(tm2048, "TM2048", "i8", 0, 524288, 23.5, 8.4, build, 4.0, 25)
+    assert valu and abs(valu["achieved"] - 4.3e9 * 4 / 23.5e-3 / 1e9) < 1e-6 and roof["traffic"] == 3.1e8 * 4
+    roof, valu = b.roofline_of(tm2048, "TM2048", "i8", 0, 524288, 61.2, 25.0, build, 2.0, 25)
+    assert valu is None and "no profile of TM2048_i8_2dB_25it" in roof["valu_issue_note"]
+    assert roof["traffic"] == 3.1e8 * 4 and "TM2048_i8_4dB_25it" in roof["traffic_source"]      # bytes per frame: any operating point
+    # the rate-4/5 bit-sliced kernel re-reads its LLR planes every iteration: ITS traffic belongs to one operating point too
+    roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 0, 524288, 17.0, 8.4, build, 4.0, 25)
+    assert roof["kernel"] == "decode_ms_bs_kernel" and roof["traffic"] == 8.5e9 * 4 and "Infinity Cache" in roof["traffic_source"] and valu
+    roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 0, 524288, 37.6, 25.0, build, 2.0, 25)
+    assert roof["traffic"] is None and valu is None and "no profile of TM5120_i8_2dB_25it" in roof["traffic_note"]
 
 
 def test_the_committed_profile_names_the_build_it_was_collected_on():
