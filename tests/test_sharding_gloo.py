@@ -64,6 +64,59 @@ def test_two_rank_gloo_shards():
     assert x0 != x1                                            # different generator streams
 
 
+def _digest_worker(rank, world, port, total, q):
+    """One rank of a job whose frames are keyed by their GLOBAL index (what bench.py does on the GPU since round 4): the shard is a
+    slice of the one-process job, and the exact integer results sum over the ranks to the one-process job's."""
+    import importlib.util
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from labrador_ldpc_amd.sharding import reduce_sum_int
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("_bench_under_test", os.path.join(root, "bench.py"))
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        code = 2                                               # TC512
+        llrs, _ = oracle.awgn_llrs(code, np.random.default_rng(77), total, 2.0, np.float32)     # THE job: every rank can name any frame of it
+        start, count = shard_range(total, world, rank)
+        out, iters, ok, _ = oracle.decode_ms_batch(code, llrs[start:start + count], 25, 1)
+
+        class W(b.Workload):
+            def __init__(self):
+                self.first_frame, self.frames = start, count
+                self.out, self.iters, self.succ = torch.from_numpy(out), torch.from_numpy(iters.astype(np.int32)), torch.from_numpy(ok.astype(np.uint8))
+        it_sum, fails, digest = reduce_sum_int(list(W().sums()))
+        q.put((rank, it_sum, fails, digest % b.DIGEST_MOD))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_job_results_are_equal_for_one_and_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    seen = []
+    for world in (1, 2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_digest_worker, args=(r, world, port, 41, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert len({r[1:] for r in res}) == 1                   # every rank holds the same job-wide sums
+        seen.append(res[0][1:])
+    assert seen[0] == seen[1] and seen[0][0] > 0, seen           # ... and the 2-rank job IS the 1-rank job
+
+
 PROBE = r'''
 import json, os, sys
 sys.path.insert(0, sys.argv[1])
