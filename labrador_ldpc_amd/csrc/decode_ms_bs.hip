@@ -1,10 +1,12 @@
 // decode_ms_bs.hip -- gfx950 instantiation of the bit-sliced i8 min-sum decoder (decode_ms_bitslice.hpp;
 // decode_ms::<i8>, /root/reference/src/decoder.rs:42-50, :347-475) for the TM codes, and its launcher.
 //
-// One wave per workgroup, one group of G = 64 / (M/32) codewords per workgroup: a codeword never leaves its wave, so the
-// kernel has no barrier, and the hardware dispatcher is the work queue (decodes take 3..25 iterations; a finished wave
-// makes room for the next group at once).  LDS per workgroup: the LLRs as bit planes (n bytes per codeword, the size of
-// the raw LLRs), a 2 KB staging slab, one word per lane and block column for the hard decisions.
+// One wave per workgroup, one group of G = 64 / (M/32) codewords per wave at a time: a codeword never leaves its wave, so the
+// kernel has no barrier.  Rate 1/2 and 2/3: one group per workgroup -- the hardware dispatcher is the work queue (decodes take
+// 3..25 iterations; a finished wave makes room for the next group at once); LDS per workgroup: the LLRs as bit planes (n bytes per
+// codeword, the size of the raw LLRs), a 2 KB staging slab, the lane-permutation table, one word per lane and block column for
+// the hard decisions.  Rate 4/5: persistent waves (the resident set), each with a 20 KB slot of a stream-ordered global
+// workspace for its LLR planes, groups dealt with a fixed stride (decode_ms_bitslice.hpp, "register diet").
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>

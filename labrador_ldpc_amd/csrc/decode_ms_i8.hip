@@ -52,8 +52,11 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
         if ((uintptr_t)llrs % 4) return hipErrorInvalidConfiguration;        // (its loads are dwords)
         return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
     }
-    if (variant == 0 && lflags == 0 && bitslice_default(code, llrs, batch, stream))
-        return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
+    if (variant == 0 && lflags == 0 && bitslice_default(code, llrs, batch, stream)) {
+        const hipError_t e = launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
+        if (e != hipErrorOutOfMemory && e != hipErrorNotSupported) return e;
+        (void)hipGetLastError();             // no stream-ordered workspace on this device / out of memory: the f32-pipe kernel needs none
+    }
     // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
         if (code == TM8192) return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);

@@ -78,3 +78,19 @@ def test_bitsliced_kernel_equals_the_default_i8_kernel_on_a_large_batch(code):
     assert 0.5 < float(a[2].float().mean()) <= 1.0
     small = llrs[:777]                                          # below the threshold the default is the f32-pipe kernel: same results
     assert all(torch.equal(x, y[:777]) for x, y in zip(code.decode_ms_batch(small, 25), a))
+
+
+def test_variant_64_is_refused_where_it_does_not_exist():
+    """The bit-sliced kernel is built for i8 on the TM codes: `variant` 64 on a TC code, or with an LLR buffer that is not 4-byte
+    aligned, reports EUNSUPPORTED (never a silent other kernel); the default dispatch takes the f32-pipe kernel for such a buffer."""
+    from labrador_ldpc_amd import LdpcHipError
+    code = LDPCCode.TC512
+    llrs = np.ones((64, code.n()), np.int8)
+    with pytest.raises(LdpcHipError):
+        code.decode_ms_batch(llrs, 5, variant=BS)
+    code = LDPCCode.TM2048
+    dev = torch.device("cuda", 0)
+    raw = torch.ones(9000 * code.n() + 1, dtype=torch.int8, device=dev)
+    odd = raw[1:].view(9000, code.n())                          # device buffer at an odd address
+    with pytest.raises(LdpcHipError):
+        code.decode_ms_batch(odd, 5, variant=BS)                # refused before anything is launched

@@ -75,3 +75,40 @@ def test_no_spill_traffic_inside_the_iteration_loops(built_objects):
                 n = sum(1 for t in sp if t.startswith("scratch_"))
                 assert n == 0, f"{kernel}: {n} scratch instructions inside an iteration loop"
     assert seen >= 100
+
+
+def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
+    """The bit-sliced kernels have no barrier to find their loops by; their iteration is what lies between the first and the last
+    ds_bpermute_b32 of a kernel (the lane permutations of the pi_k blocks).  The rate-4/5 instantiations are compiled at a forced 256
+    registers and report ~105 spilled registers: all of them in the prologue / epilogue (LLR transposition, output packing) -- the
+    7 000-instruction iteration must not touch scratch memory."""
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tmp = tempfile.mkdtemp()
+    obj = os.path.join(ROOT, "build", "csrc", "decode_ms_bs.o")
+    subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", obj, "/dev/null"])
+    subprocess.check_call([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat",
+                           f"--output={tmp}/co", "--unbundle"])
+    dis = subprocess.check_output([f"{llvm}/llvm-objdump", "-d", f"{tmp}/co"], text=True).split("\n")
+    kernels, cur = {}, None
+    for line in dis:
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur and "\t" in line:
+            kernels[cur].append(line.split("//")[0].strip())
+    seen = 0
+    for name, body in kernels.items():
+        if "decode_ms_bs_kernel" not in name:
+            continue
+        perm = [i for i, t in enumerate(body) if t.startswith("ds_bpermute_b32")]
+        assert len(perm) >= 100, name
+        loop = body[perm[0]:perm[-1]]
+        n = sum(1 for t in loop if t.startswith("scratch_"))
+        assert n == 0, f"{name}: {n} scratch instructions inside the iteration"
+        assert sum(1 for t in loop if t.startswith("v_bitop3_b32")) > 0.6 * len(loop) - 200      # ... which is Boolean arithmetic
+        seen += 1
+    assert seen == 6
