@@ -169,8 +169,16 @@ hipError_t launch_decode_bf(int code, const uint8_t *input, uint8_t *output, uin
     // LABRADOR_LDPC_HIP_BF_BYTES=1 forces the byte-per-variable kernel (A/B timing, tests).
     static const bool force_bytes = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_BF_BYTES"); return e && *e && *e != '0'; }();
     if (!force_bytes && code >= TM1280 && code <= TM8192 && (uintptr_t)input % 4 == 0 && (uintptr_t)output % 4 == 0 &&
-        batch >= (size_t)BF_BITSLICE_MIN_GROUPS * (size_t)(64 / (CODES[code].m / 32)))
-        return launch_decode_bf_bitsliced(code, input, output, iters, success, batch, maxiters, stream);
+        batch >= (size_t)BF_BITSLICE_MIN_GROUPS * (size_t)(64 / (CODES[code].m / 32))) {
+        // (its queue head is a stream-ordered allocation: not inside a graph capture, not on the per-thread default stream)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const bool plain = stream != hipStreamPerThread && (stream == nullptr || (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusNone));
+        if (plain) {
+            const hipError_t e = launch_decode_bf_bitsliced(code, input, output, iters, success, batch, maxiters, stream);
+            if (e != hipErrorOutOfMemory && e != hipErrorNotSupported) return e;
+            (void)hipGetLastError();
+        }
+    }
     switch (code) {
         case TC128:  return launch<TC128>(input, output, iters, success, batch, maxiters, stream);
         case TC256:  return launch<TC256>(input, output, iters, success, batch, maxiters, stream);

@@ -9,15 +9,25 @@
 namespace ldpc {
 namespace bs {
 
+// (the rate-4/5 codes: 39 edges' permutations and 11 columns of counters do not fit the 128 registers of four waves per SIMD)
+template <int CODE> constexpr int bf_waves_per_simd() { return (CODE == TM1280 || CODE == TM5120) ? 2 : 4; }
+
 template <int CODE>
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, bf_waves_per_simd<CODE>())
 decode_bf_bs_kernel(const uint8_t *__restrict__ input, uint8_t *__restrict__ output, uint32_t *__restrict__ iters, uint8_t *__restrict__ success,
-                    uint32_t batch, uint32_t maxiters, uint32_t ngroups)
+                    uint32_t batch, uint32_t maxiters, uint32_t ngroups, uint32_t *__restrict__ queue)
 {
     __shared__ __attribute__((aligned(16))) char lds[BfGeo<CODE>::LDS_BYTES];
     HipBackend b{lds};
     bf_init_kernel<CODE, HipBackend>(b);
-    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) bf_decode_group<CODE, HipBackend>(b, input, output, iters, success, batch, maxiters, g);
+    // persistent waves fed from a queue (a decode is a few microseconds and data dependent; the waves of a CU do not run at one speed)
+    uint32_t g = blockIdx.x;
+    while (g < ngroups) {
+        bf_decode_group<CODE, HipBackend>(b, input, output, iters, success, batch, maxiters, g);
+        uint32_t t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(queue, 1u);
+        g = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    }
 }
 
 template <int CODE>
@@ -27,11 +37,18 @@ hipError_t launch_bf(const uint8_t *input, uint8_t *output, uint32_t *iters, uin
     if (batch == 0) return hipSuccess;
     if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const size_t groups = (batch + G - 1) / G;
-    // persistent waves: 16 per CU x 256 CUs cover the chip; a decode is a few microseconds, so the groups are dealt with a fixed stride
+    // persistent waves: 16 per CU x 256 CUs cover the chip; the queue head is a stream-ordered 256-byte allocation
     const size_t grid = groups < 16384 ? groups : 16384;
+    uint32_t *queue = nullptr;
+    hipError_t e = hipMallocAsync((void **)&queue, 256, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(queue, 0, 256, stream);
+    if (e != hipSuccess) { (void)hipFreeAsync(queue, stream); return e; }
     hipLaunchKernelGGL((decode_bf_bs_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, input, output, iters, success, (uint32_t)batch, maxiters,
-                       (uint32_t)groups);
-    return hipGetLastError();
+                       (uint32_t)groups, queue);
+    e = hipGetLastError();
+    const hipError_t e2 = hipFreeAsync(queue, stream);
+    return e != hipSuccess ? e : e2;
 }
 
 }  // namespace bs

@@ -6,7 +6,7 @@
 // 3..25 iterations; a finished wave makes room for the next group at once); LDS per workgroup: the LLRs as bit planes (n bytes per
 // codeword, the size of the raw LLRs), a 2 KB staging slab, the lane-permutation table, one word per lane and block column for
 // the hard decisions.  Rate 4/5: persistent waves (the resident set), each with a 20 KB slot of a stream-ordered global
-// workspace for its LLR planes, groups dealt with a fixed stride (decode_ms_bitslice.hpp, "register diet").
+// workspace for its LLR planes, groups drawn from a queue head at the start of that workspace (decode_ms_bitslice.hpp, "register diet").
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
@@ -22,6 +22,8 @@ namespace bs {
 // rate-4/5 codes' state (39 edges: ~250 planes before any temporary) needs the whole file of one wave per SIMD
 template <int CODE> constexpr int waves_per_simd() { return 2; }
 
+constexpr int WS_HEADER_WORDS = 64;          // the queue head, on a 256-byte line of its own
+
 template <int CODE>
 __global__ void __launch_bounds__(64, waves_per_simd<CODE>())
 decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters,
@@ -30,8 +32,22 @@ decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ outpu
     __shared__ __attribute__((aligned(16))) char lds[Geo<CODE>::LDS_BYTES];
     HipBackend b{lds};
     init_kernel<CODE, HipBackend>(b);
-    uint32_t *ws = Geo<CODE>::LLR_GLOBAL ? workspace + (size_t)blockIdx.x * Geo<CODE>::LLR_WORDS : nullptr;      // this wave's slot
-    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g, ws);
+    if constexpr (Geo<CODE>::LLR_GLOBAL) {
+        // persistent waves, fed from a queue: the workspace starts with the queue head (zeroed by the launcher), this wave's slot of LLR
+        // planes follows.  A wave's first group is its own index; every further one is drawn with one atomic.  (A fixed stride lost 7-14 %
+        // even where every frame takes the same 25 iterations -- the waves of a CU do not run at one speed -- and 40 % on a box whose
+        // chip was unevenly clocked: profiles/r04_kbench/r45_queue_ab.txt.)
+        uint32_t *ws = workspace + WS_HEADER_WORDS + (size_t)blockIdx.x * Geo<CODE>::LLR_WORDS;
+        uint32_t g = blockIdx.x;
+        while (g < ngroups) {
+            decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g, ws);
+            uint32_t t = 0;
+            if ((threadIdx.x & 63) == 0) t = atomicAdd(workspace, 1u);
+            g = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        }
+    } else {
+        for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g, nullptr);
+    }
 }
 
 template <int CODE>
@@ -44,8 +60,7 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
     size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
     uint32_t *ws = nullptr;
     if constexpr (Geo<CODE>::LLR_GLOBAL) {
-        // persistent waves, one workspace slot each: the grid is the resident set (the groups are dealt with a fixed stride;
-        // a wave decodes dozens of them, so the data-dependent iteration counts average out)
+        // persistent waves, one workspace slot each: the grid is the resident set, the groups are drawn from a queue (kernel)
         static std::atomic<int> cached[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -58,8 +73,10 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
             cached[dev].store(resident, std::memory_order_relaxed);
         }
         if (grid > (size_t)resident) grid = (size_t)resident;
-        const hipError_t e = hipMallocAsync((void **)&ws, grid * Geo<CODE>::LLR_WORDS * sizeof(uint32_t), stream);
+        hipError_t e = hipMallocAsync((void **)&ws, (WS_HEADER_WORDS + grid * Geo<CODE>::LLR_WORDS) * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
+        e = hipMemsetAsync(ws, 0, WS_HEADER_WORDS * sizeof(uint32_t), stream);
+        if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return e; }
     }
     hipLaunchKernelGGL((decode_ms_bs_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
                        (uint32_t)groups, ws);
