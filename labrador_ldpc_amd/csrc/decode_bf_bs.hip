@@ -10,6 +10,8 @@ namespace ldpc {
 namespace bs {
 
 // (the rate-4/5 codes: 39 edges' permutations and 11 columns of counters do not fit the 128 registers of four waves per SIMD)
+constexpr uint32_t BF_CHUNK = 4;             // groups per queue draw
+
 template <int CODE> constexpr int bf_waves_per_simd() { return (CODE == TM1280 || CODE == TM5120) ? 2 : 4; }
 
 template <int CODE>
@@ -20,13 +22,17 @@ decode_bf_bs_kernel(const uint8_t *__restrict__ input, uint8_t *__restrict__ out
     __shared__ __attribute__((aligned(16))) char lds[BfGeo<CODE>::LDS_BYTES];
     HipBackend b{lds};
     bf_init_kernel<CODE, HipBackend>(b);
-    // persistent waves fed from a queue (a decode is a few microseconds and data dependent; the waves of a CU do not run at one speed)
-    uint32_t g = blockIdx.x;
-    while (g < ngroups) {
-        bf_decode_group<CODE, HipBackend>(b, input, output, iters, success, batch, maxiters, g);
+    // persistent waves fed from a queue (a decode is a few microseconds and data dependent; the waves of a CU do not run at one speed).
+    // A draw takes BF_CHUNK consecutive groups: same-address atomics complete at ~85 M per second on this device, which
+    // one group per draw reaches -- TM2048 342 M codewords/s = 85 M groups/s, TM8192 85 M -- and four per draw stay clear of.
+    const uint32_t nchunks = (ngroups + BF_CHUNK - 1) / BF_CHUNK;
+    uint32_t c = blockIdx.x;
+    while (c < nchunks) {
+        const uint32_t g1 = (c + 1) * BF_CHUNK < ngroups ? (c + 1) * BF_CHUNK : ngroups;
+        for (uint32_t g = c * BF_CHUNK; g < g1; ++g) bf_decode_group<CODE, HipBackend>(b, input, output, iters, success, batch, maxiters, g);
         uint32_t t = 0;
         if ((threadIdx.x & 63) == 0) t = atomicAdd(queue, 1u);
-        g = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        c = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     }
 }
 
@@ -38,7 +44,8 @@ hipError_t launch_bf(const uint8_t *input, uint8_t *output, uint32_t *iters, uin
     if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const size_t groups = (batch + G - 1) / G;
     // persistent waves: 16 per CU x 256 CUs cover the chip; the queue head is a stream-ordered 256-byte allocation
-    const size_t grid = groups < 16384 ? groups : 16384;
+    const size_t chunks = (groups + BF_CHUNK - 1) / BF_CHUNK;
+    const size_t grid = chunks < 16384 ? chunks : 16384;
     uint32_t *queue = nullptr;
     hipError_t e = hipMallocAsync((void **)&queue, 256, stream);
     if (e != hipSuccess) return e;
