@@ -10,7 +10,9 @@ namespace ldpc {
 namespace bs {
 
 // (the rate-4/5 codes: 39 edges' permutations and 11 columns of counters do not fit the 128 registers of four waves per SIMD)
-constexpr uint32_t BF_CHUNK = 4;             // groups per queue draw
+// groups per queue draw: four, except for the rate-4/5 codes -- their longer decodes (39 edges) stay far below the atomics' ceiling with
+// one, and fewer, larger chunks cost them 12-15 % in the tail (TM5120 123 against 109 M codewords/s, TM1280 211 against 181)
+template <int CODE> constexpr uint32_t bf_chunk() { return (CODE == TM1280 || CODE == TM5120) ? 1u : 4u; }
 
 template <int CODE> constexpr int bf_waves_per_simd() { return (CODE == TM1280 || CODE == TM5120) ? 2 : 4; }
 
@@ -23,8 +25,9 @@ decode_bf_bs_kernel(const uint8_t *__restrict__ input, uint8_t *__restrict__ out
     HipBackend b{lds};
     bf_init_kernel<CODE, HipBackend>(b);
     // persistent waves fed from a queue (a decode is a few microseconds and data dependent; the waves of a CU do not run at one speed).
-    // A draw takes BF_CHUNK consecutive groups: same-address atomics complete at ~85 M per second on this device, which
+    // A draw takes bf_chunk<CODE>() consecutive groups: same-address atomics complete at ~85 M per second on this device, which
     // one group per draw reaches -- TM2048 342 M codewords/s = 85 M groups/s, TM8192 85 M -- and four per draw stay clear of.
+    constexpr uint32_t BF_CHUNK = bf_chunk<CODE>();
     const uint32_t nchunks = (ngroups + BF_CHUNK - 1) / BF_CHUNK;
     uint32_t c = blockIdx.x;
     while (c < nchunks) {
@@ -44,7 +47,7 @@ hipError_t launch_bf(const uint8_t *input, uint8_t *output, uint32_t *iters, uin
     if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const size_t groups = (batch + G - 1) / G;
     // persistent waves: 16 per CU x 256 CUs cover the chip; the queue head is a stream-ordered 256-byte allocation
-    const size_t chunks = (groups + BF_CHUNK - 1) / BF_CHUNK;
+    const size_t chunks = (groups + bf_chunk<CODE>() - 1) / bf_chunk<CODE>();
     const size_t grid = chunks < 16384 ? chunks : 16384;
     uint32_t *queue = nullptr;
     hipError_t e = hipMallocAsync((void **)&queue, 256, stream);
