@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -151,6 +152,106 @@ encode_kernel_k4096(const uint32_t *__restrict__ gt, const uint8_t *__restrict__
     }
 }
 
+// k = 4096, round 4: TWO parity columns per thread over HALF of k.  The kernel above is bound by its LDS broadcasts, not by its
+// arithmetic: a wave spends 32 ds_read_b128 (1.79 ns each on the CU's one LDS pipe: 57 ns) on the 128 v_bitop3 (141 ns on its SIMD) of a
+// frame, and with eight waves per CU that is 458 ns of LDS against 282 ns of VALU per eight wave-frames (profiles/r04_final/frow_table.md:
+// 49.8 M codewords/s = 71 % of that LDS bound).  A data word read once can feed two columns: threads 0-127 own columns (t, t + 128) of the
+// workgroup's 256 over data words 0-63, threads 128-255 the same columns over words 64-127 -- the same 128 generator registers and the same
+// 128 v_bitop3 per thread and frame, HALF the broadcasts.  The two halves' parities meet in LDS once per eight-frame group (the wave
+// ballots, 1 KB, double-buffered behind the group loop's existing barrier) and 32 threads combine, bit-reverse and store them.
+// Measured (profiles/r04_kbench/enc_variants.txt): 53.5 -> 62.4-64.5 M codewords/s TM8192, 190 -> 224-232 M TM5120.  Tried on top and
+// dropped: 16- and 32-frame groups (-9..-12 %), four accumulators per column (+-1 %), issuing the broadcasts a 32-op chunk ahead
+// (-5 %), the combine spread over the four waves (+-0.5 %).  What remains is the v_bitop3 issue itself: 128 per thread and frame.
+__global__ void __launch_bounds__(256, 2)
+encode_kernel_k4096_2col(const uint32_t *__restrict__ gt, const uint8_t *__restrict__ data, uint8_t *__restrict__ codewords,
+                         uint32_t batch, uint32_t n_bytes, uint32_t n_parity, uint32_t frames_per_wg, uint32_t xcd_remap)
+{
+    constexpr int KW = 128, KB = 512, FB = 8, HW = KW / 2;
+    // Which (column group cx, frame range cy) this workgroup takes.  Workgroups are dealt round-robin over the eight XCDs in launch
+    // order (x fastest), so with the plain (blockIdx.x, blockIdx.y) assignment the gridDim.x column groups of ONE frame range sit on
+    // different XCDs: each XCD's L2 fetches those frames' data for itself and writes its 32-byte pieces of their parity lines on its
+    // own.  With the remap the workgroups that share an XCD (equal launch index mod 8) enumerate cx fastest, so one frame range's
+    // column groups run side by side on one L2: the data is fetched once and the parity lines are completed there.  Placement is a
+    // matter of memory traffic only (any bijection is correct, and the kernel's time does not depend on it: it is bound by its
+    // v_bitop3 issue); it needs gridDim.y to be a multiple of 8.
+    uint32_t cx = blockIdx.x, cy = blockIdx.y;
+    if (xcd_remap) {
+        const uint32_t li = blockIdx.y * gridDim.x + blockIdx.x, slot = li >> 3;
+        cx = slot % gridDim.x;
+        cy = (slot / gridDim.x) * 8 + (li & 7);
+    }
+    __shared__ uint4 stage[2][FB * KB / 16];
+    __shared__ unsigned long long part[2][2][FB][2][2];         // [buffer][k half][frame][wave of the half][column set]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t half = tid >> 7, t = tid & 127, wv = t >> 6;
+    const uint32_t base = cx * 256;
+    const uint32_t pa = base + t, pb = base + 128 + t;           // (n_parity is a multiple of 256 here)
+    uint32_t ga[HW], gb[HW];
+#pragma unroll
+    for (int w = 0; w < HW; ++w) {
+        ga[w] = gt[(size_t)pa * KW + half * HW + w];
+        gb[w] = gt[(size_t)pb * KW + half * HW + w];
+    }
+    const uint32_t f_begin = cy * frames_per_wg;
+    if (f_begin >= batch) return;                               // (uniform over the workgroup)
+    const uint32_t f_end = f_begin + frames_per_wg < batch ? f_begin + frames_per_wg : batch;
+    auto load_group = [&](uint32_t fg) -> uint4 {               // this thread's 16 bytes of the 8 frames from fg on
+        if (fg + tid / 32 >= batch) return uint4{0u, 0u, 0u, 0u};
+        return *reinterpret_cast<const uint4 *>(data + (size_t)fg * KB + tid * 16);
+    };
+    auto combine = [&](int b, uint32_t fg, uint32_t nf) {       // threads 0..31: one (frame, wave, column set) each
+        if (tid < 32) {
+            const uint32_t j = tid >> 2, w = (tid >> 1) & 1, sset = tid & 1;
+            if (j < nf) {
+                const unsigned long long m = part[b][0][j][w][sset] ^ part[b][1][j][w][sset];      // bit l = column base + 128 sset + 64 w + l
+                const unsigned lo = __builtin_bswap32(__builtin_bitreverse32((unsigned)m));
+                const unsigned hi = __builtin_bswap32(__builtin_bitreverse32((unsigned)(m >> 32)));
+                uint32_t *dst = reinterpret_cast<uint32_t *>(codewords + (size_t)(fg + j) * n_bytes + KB + (base + 128 * sset + 64 * w) / 8);
+                dst[0] = lo;
+                dst[1] = hi;
+            }
+        }
+    };
+    uint4 r = load_group(f_begin);
+    int buf = 0;
+    stage[0][tid] = r;
+    __syncthreads();
+    uint32_t prev_fg = 0, prev_nf = 0;
+    for (uint32_t fg = f_begin; fg < f_end; fg += FB) {
+        const bool more = fg + FB < f_end;
+        if (more) r = load_group(fg + FB);
+        if (prev_nf) combine(buf ^ 1, prev_fg, prev_nf);       // the previous group's parities, complete since the barrier below
+        const uint32_t nf = f_end - fg < (uint32_t)FB ? f_end - fg : (uint32_t)FB;
+        for (uint32_t j = 0; j < nf; ++j) {
+            const uint4 *fr = &stage[buf][j * (KB / 16) + half * (HW / 4)];
+            uint32_t a2[2] = {0u, 0u}, b2[2] = {0u, 0u};
+#pragma unroll
+            for (int w4 = 0; w4 < HW / 4; ++w4) {
+                const uint4 dv = fr[w4];                                                  // same address in every lane of a half
+                a2[0] = __builtin_amdgcn_bitop3_b32(a2[0], ga[4 * w4 + 0], dv.x, 0x78);  // acc ^ (g & d)
+                b2[0] = __builtin_amdgcn_bitop3_b32(b2[0], gb[4 * w4 + 0], dv.x, 0x78);
+                a2[1] = __builtin_amdgcn_bitop3_b32(a2[1], ga[4 * w4 + 1], dv.y, 0x78);
+                b2[1] = __builtin_amdgcn_bitop3_b32(b2[1], gb[4 * w4 + 1], dv.y, 0x78);
+                a2[0] = __builtin_amdgcn_bitop3_b32(a2[0], ga[4 * w4 + 2], dv.z, 0x78);
+                b2[0] = __builtin_amdgcn_bitop3_b32(b2[0], gb[4 * w4 + 2], dv.z, 0x78);
+                a2[1] = __builtin_amdgcn_bitop3_b32(a2[1], ga[4 * w4 + 3], dv.w, 0x78);
+                b2[1] = __builtin_amdgcn_bitop3_b32(b2[1], gb[4 * w4 + 3], dv.w, 0x78);
+            }
+            const unsigned long long ma = __ballot(__builtin_popcount(a2[0] ^ a2[1]) & 1);
+            const unsigned long long mb = __ballot(__builtin_popcount(b2[0] ^ b2[1]) & 1);
+            if ((tid & 63) == 0) { part[buf][half][j][wv][0] = ma; part[buf][half][j][wv][1] = mb; }
+        }
+        // systematic part: the first column group copies the staged data bytes
+        if (cx == 0 && fg + tid / 32 < f_end)
+            *reinterpret_cast<uint4 *>(codewords + (size_t)(fg + tid / 32) * n_bytes + (tid % 32) * 16) = stage[buf][tid];
+        if (more) stage[buf ^ 1][tid] = r;
+        __syncthreads();
+        prev_fg = fg; prev_nf = nf;
+        buf ^= 1;
+    }
+    if (prev_nf) combine(buf ^ 1, prev_fg, prev_nf);
+}
+
 struct DeviceGenerator {
     uint32_t *gt = nullptr;
 };
@@ -208,7 +309,7 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
     // uncached runtime queries per launch (the decode launchers cache the same quantity: resident_workgroups())
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    static std::atomic<int> cached_cus[64] = {}, cached_occ[64][6] = {};         // [device][kernel]; concurrent fills store the same value
+    static std::atomic<int> cached_cus[64] = {}, cached_occ[64][7] = {};         // [device][kernel]; concurrent fills store the same value
     int cus = cached_cus[dev].load(std::memory_order_relaxed);
     if (cus == 0) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -242,7 +343,20 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
     if (gy < 1) gy = 1;
     const dim3 grid(gx, gy);
     if (ci.k == 4096 && (uintptr_t)data % 16 == 0 && (uintptr_t)codewords % 16 == 0 && np % 256 == 0) {
-        // LDS-staged kernel: contiguous runs of frames per workgroup, a multiple of its 8-frame stage
+        // LDS-staged kernels: contiguous runs of frames per workgroup, a multiple of their 8-frame stage.  Default: two columns per thread
+        // over half of k (half the LDS broadcasts per v_bitop3); LABRADOR_LDPC_HIP_ENC_1COL=1 selects round 2's one column over all of k.
+        static const bool one_col = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_ENC_1COL"); return e && *e && *e != '0'; }();
+        if (!one_col) {
+            const int pc = occupancy((const void *)encode_kernel_k4096_2col, 6);
+            unsigned gy3 = (unsigned)(cus * pc) / gx > 0 ? (unsigned)(cus * pc) / gx : 1;
+            size_t per_wg3 = (batch + gy3 - 1) / gy3;
+            per_wg3 = (per_wg3 + 7) / 8 * 8;
+            gy3 = (unsigned)((batch + per_wg3 - 1) / per_wg3);
+            static const bool plain_map = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_ENC_PLAIN_MAP"); return e && *e && *e != '0'; }();
+            const uint32_t remap = (!plain_map && gy3 % 8 == 0) ? 1u : 0u;
+            hipLaunchKernelGGL(encode_kernel_k4096_2col, dim3(gx, gy3), dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, (uint32_t)per_wg3, remap);
+            return hipGetLastError();
+        }
         const int per_cu2 = occupancy((const void *)encode_kernel_k4096, 5);
         unsigned gy2 = (unsigned)(cus * per_cu2) / gx > 0 ? (unsigned)(cus * per_cu2) / gx : 1;
         size_t per_wg = (batch + gy2 - 1) / gy2;
