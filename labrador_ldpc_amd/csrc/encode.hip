@@ -29,16 +29,24 @@ __global__ void __launch_bounds__(256)
 encode_kernel(const uint32_t *__restrict__ gt,     // [n-k][KW] generator columns, bit layout of a LE dword load
               const uint8_t *__restrict__ data,    // [batch][k/8]
               uint8_t *__restrict__ codewords,     // [batch][n/8]
-              uint32_t batch, uint32_t n_bytes, uint32_t n_parity)
+              uint32_t batch, uint32_t n_bytes, uint32_t n_parity, uint32_t xcd_remap)
 {
     constexpr int KB = KW * 4;                     // data bytes per frame
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;          // parity column
+    // (column group cx, frame residue cy) of this workgroup: with xcd_remap the column groups of one frame run on one XCD (see
+    // encode_kernel_k4096_2col below) -- one L2 fetches the frame's data and completes its parity lines
+    uint32_t cx = blockIdx.x, cy = blockIdx.y;
+    if (xcd_remap) {
+        const uint32_t li = blockIdx.y * gridDim.x + blockIdx.x, slot = li >> 3;
+        cx = slot % gridDim.x;
+        cy = (slot / gridDim.x) * 8 + (li & 7);
+    }
+    const uint32_t p = cx * 256 + threadIdx.x;                  // parity column
     const bool active = p < n_parity;
     uint32_t g[KW];
 #pragma unroll
     for (int w = 0; w < KW; ++w) g[w] = active ? gt[(size_t)p * KW + w] : 0u;
 
-    for (uint32_t f = blockIdx.y; f < batch; f += gridDim.y) {
+    for (uint32_t f = cy; f < batch; f += gridDim.y) {
         const uint32_t *d = reinterpret_cast<const uint32_t *>(data + (size_t)f * KB);   // wave-uniform
         // The data words are wave-uniform and arrive through the scalar cache in chunks of CH dwords; a chunk's
         // load is issued one chunk AHEAD of its use (two sets of SGPRs), otherwise every chunk costs the wave a
@@ -82,7 +90,7 @@ encode_kernel(const uint32_t *__restrict__ gt,     // [n-k][KW] generator column
             }
         }
         // systematic part: the first workgroup column copies the data bytes
-        if (blockIdx.x == 0)
+        if (cx == 0)
             for (uint32_t b = threadIdx.x; b < (uint32_t)KW; b += 256)
                 reinterpret_cast<uint32_t *>(codewords + (size_t)f * n_bytes)[b] = d[b];
     }
@@ -340,8 +348,11 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
     unsigned gy = ((unsigned)(cus * per_cu) * rounds + gx - 1) / gx;
     if (ci.k >= 4096) gy = (unsigned)(cus * per_cu) / gx > 0 ? (unsigned)(cus * per_cu) / gx : 1;
     if (gy > batch) gy = (unsigned)batch;
+    if (gy >= 8 && gx > 1) gy -= gy % 8;                         // the XCD-aware workgroup map needs a multiple of 8
     if (gy < 1) gy = 1;
     const dim3 grid(gx, gy);
+    static const bool plain_map = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_ENC_PLAIN_MAP"); return e && *e && *e != '0'; }();
+    const uint32_t remap_g = (!plain_map && gx > 1 && gy % 8 == 0) ? 1u : 0u;
     if (ci.k == 4096 && (uintptr_t)data % 16 == 0 && (uintptr_t)codewords % 16 == 0 && np % 256 == 0) {
         // LDS-staged kernels: contiguous runs of frames per workgroup, a multiple of their 8-frame stage.  Default: two columns per thread
         // over half of k (half the LDS broadcasts per v_bitop3); LABRADOR_LDPC_HIP_ENC_1COL=1 selects round 2's one column over all of k.
@@ -352,7 +363,6 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
             size_t per_wg3 = (batch + gy3 - 1) / gy3;
             per_wg3 = (per_wg3 + 7) / 8 * 8;
             gy3 = (unsigned)((batch + per_wg3 - 1) / per_wg3);
-            static const bool plain_map = [] { const char *e = std::getenv("LABRADOR_LDPC_HIP_ENC_PLAIN_MAP"); return e && *e && *e != '0'; }();
             const uint32_t remap = (!plain_map && gy3 % 8 == 0) ? 1u : 0u;
             hipLaunchKernelGGL(encode_kernel_k4096_2col, dim3(gx, gy3), dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, (uint32_t)per_wg3, remap);
             return hipGetLastError();
@@ -366,11 +376,11 @@ hipError_t launch_encode(int code, const uint8_t *data, uint8_t *codewords, size
         return hipGetLastError();
     }
     switch (ci.k / 32) {
-        case 2:   hipLaunchKernelGGL((encode_kernel<2>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
-        case 4:   hipLaunchKernelGGL((encode_kernel<4>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
-        case 8:   hipLaunchKernelGGL((encode_kernel<8>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
-        case 32:  hipLaunchKernelGGL((encode_kernel<32>),  grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
-        case 128: hipLaunchKernelGGL((encode_kernel<128>), grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np); break;
+        case 2:   hipLaunchKernelGGL((encode_kernel<2>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, remap_g); break;
+        case 4:   hipLaunchKernelGGL((encode_kernel<4>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, remap_g); break;
+        case 8:   hipLaunchKernelGGL((encode_kernel<8>),   grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, remap_g); break;
+        case 32:  hipLaunchKernelGGL((encode_kernel<32>),  grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, remap_g); break;
+        case 128: hipLaunchKernelGGL((encode_kernel<128>), grid, dim3(256), 0, stream, gt, data, codewords, (uint32_t)batch, nb, np, remap_g); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

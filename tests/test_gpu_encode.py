@@ -53,6 +53,20 @@ def test_encode_batch_device_tensors_and_round_trip():
         assert float(same[okb].float().mean()) > 0.999
 
 
+@pytest.mark.parametrize("code", [LDPCCode.TM2048, LDPCCode.TM5120, LDPCCode.TM6144, LDPCCode.TM8192], ids=lambda c: c.name)
+def test_encode_batch_resident_grid_every_workgroup(code):
+    """A batch that fills the resident grid (the XCD-aware workgroup map of csrc/encode.hip is on: grid.y a multiple of 8) with a
+    ragged last frame range: frames from every workgroup's range against the oracle, bit for bit."""
+    rng = np.random.default_rng(300 + int(code))
+    B = 4091
+    data = rng.integers(0, 256, (B, code.k() // 8), dtype=np.uint8)
+    cw = code.encode_batch(data)
+    assert cw.shape == (B, code.n() // 8)
+    assert (cw[:, : code.k() // 8] == data).all()
+    for f in list(range(0, B, 5)) + list(range(B - 140, B)):
+        assert (cw[f] == oracle.copy_encode(code, data[f])).all(), f"frame {f}"
+
+
 def test_empty_and_bad_arguments():
     code = LDPCCode.TC128
     assert code.encode_batch(np.zeros((0, code.k() // 8), dtype=np.uint8)).shape == (0, code.n() // 8)
