@@ -9,11 +9,11 @@
 namespace ldpc {
 namespace bs {
 
-// (the rate-4/5 codes: 39 edges' permutations and 11 columns of counters do not fit the 128 registers of four waves per SIMD)
 // groups per queue draw: four, except for the rate-4/5 codes -- their longer decodes (39 edges) stay far below the atomics' ceiling with
 // one, and fewer, larger chunks cost them 12-15 % in the tail (TM5120 123 against 109 M codewords/s, TM1280 211 against 181)
 template <int CODE> constexpr uint32_t bf_chunk() { return (CODE == TM1280 || CODE == TM5120) ? 1u : 4u; }
 
+// waves per SIMD: four (128 registers), two for the rate-4/5 codes, whose 39 edges' permutations and 11 columns of counters do not fit 128
 template <int CODE> constexpr int bf_waves_per_simd() { return (CODE == TM1280 || CODE == TM5120) ? 2 : 4; }
 
 template <int CODE>

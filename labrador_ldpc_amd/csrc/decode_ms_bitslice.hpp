@@ -33,6 +33,9 @@
 //
 // The code below is written against a small backend `B` (one wave's registers as values of type B::V): HipBackend compiles it
 // for gfx950, tests/bitslice_emu.cpp runs the same text lane by lane on the CPU, where it is compared with the oracle.
+//
+// BS_DIAG (never defined by the library's Makefile; tools/bs_diag_build.sh): timing-only builds that leave out one kind of memory
+// access -- wrong results -- to bound what hiding its latency could give (profiles/r04_kbench/bs_diag.txt).
 #pragma once
 
 #include <cstdint>
@@ -107,6 +110,22 @@ struct Geo {
     // ordinal of block b among the exchanged (pi_k) blocks
     static constexpr int exch_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += local(i) ? 0 : 1; return s; }
     static constexpr int NX = exch_of(NB);
+    // the order in which an iteration uses the permutation-table entries (entry 2x = check -> variable alignment of exchanged edge x,
+    // 2x + 1 = the way back): block column by block column, the variable side's edges, then the check side's
+    struct PermOrder { int idx[2 * NB + 1]; int pos[2 * NB + 1]; };
+    static constexpr PermOrder perm_order()
+    {
+        PermOrder o{};
+        int n = 0;
+        for (int c = 0; c < NCOLS; ++c)
+            for (int side = 0; side < 2; ++side)
+                for (int e = 0; e < NB; ++e)
+                    if (P.blk[e].col == c && !local(e)) o.idx[n++] = exch_of(e) * 2 + side;
+        for (int i = 0; i < n; ++i) o.pos[o.idx[i]] = i;
+        return o;
+    }
+    static constexpr PermOrder PERM_ORDER = perm_order();
+    static constexpr int perm_after(int idx) { return PERM_ORDER.idx[(PERM_ORDER.pos[idx] + 1) % (2 * NX)]; }
     // The rate-4/5 codes keep their LLR planes in a global workspace (one slot per resident wave, re-read from L2 / MALL in every
     // iteration, 20 KB per wave): in LDS they alone would take the 160 KB of a CU at two waves per SIMD.
     static constexpr bool LLR_GLOBAL = P.n_blocks > 30;
@@ -304,8 +323,22 @@ struct Decoder {
 
     template <int IDX> BS_FN V perm_entry(B &b) const
     {
+#if defined(BS_DIAG) && (BS_DIAG & 2)
+        return B::add(B::shl(lane, 2), B::c((IDX * 37) & 0x1F00));   // DIAGNOSTIC: no table read (wrong results)
+#endif
         if constexpr (GEO::PERM16) return b.lds_read_u16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)));
         else return b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + IDX * 256)));
+    }
+    // The entries are used in a fixed order (Geo::PERM_ORDER), so each use hands out the entry read during the PREVIOUS use and starts
+    // the read of the next one: an LDS round trip in front of every edge's eight ds_bpermute, with one other wave on the SIMD to hide
+    // it behind, cost 10-12 % (profiles/r04_kbench/bs_diag.txt, BS_DIAG=2).  One register.
+    V pnext;
+    BS_FN void prime_perm(B &b) { pnext = perm_entry<GEO::PERM_ORDER.idx[0]>(b); }
+    template <int IDX> BS_FN V take_perm(B &b)
+    {
+        const V a = pnext;
+        pnext = perm_entry<GEO::perm_after(IDX)>(b);
+        return a;
     }
     template <int IDX> BS_FN void put_perm_entry(B &b, V w) const
     {
@@ -390,7 +423,11 @@ struct Decoder {
                 pin(at);                              // (the loads of this column start here, not at the top of the iteration)
                 sfor<0, 8>([&](auto K_) {
                     constexpr int k = decltype(K_)::value;
+#if defined(BS_DIAG) && (BS_DIAG & 1)
+                    if constexpr (GEO::LLR_GLOBAL) va[k] = B::xor_(at, B::c(0x9E3779B9u * (c * 8 + k + 1)));      // DIAGNOSTIC: no load (wrong results)
+#else
                     if constexpr (GEO::LLR_GLOBAL) va[k] = b.gload32(ws, B::add(at, B::c((c * 8 + k) * 256)), B::c(0xFFFFFFFFu));
+#endif
                     else va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (c * 8 + k) * 256)));
                 });
             } else {
@@ -403,10 +440,15 @@ struct Decoder {
                     fill_old<GEO::P.blk[e].row>(b);
                     edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
-                        const V addr = perm_entry<GEO::exch_of(e) * 2 + 0>(b);
+                        const V addr = take_perm<GEO::exch_of(e) * 2 + 0>(b);
                         const V amt = B::shr(addr, 8);
+#if defined(BS_DIAG) && (BS_DIAG & 4)
+                        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(B::xor_(addr, mg[k]), amt); });   // DIAGNOSTIC
+                        su = B::rotr(B::xor_(addr, su), amt);
+#else
                         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
                         su = B::rotr(b.bperm(addr, su), amt);
+#endif
                     }
                     A::template sat_addsub<false>(va, su, mg);
                     sfor<0, 8>([&](auto K_) { pin(va[decltype(K_)::value]); });
@@ -424,9 +466,13 @@ struct Decoder {
                     constexpr int r = GEO::P.blk[e].row, slot = GEO::slot_of(e);
                     V nv[8];
                     if constexpr (!GEO::local(e)) {
-                        const V addr = perm_entry<GEO::exch_of(e) * 2 + 1>(b);
+                        const V addr = take_perm<GEO::exch_of(e) * 2 + 1>(b);
                         const V amt = B::shr(addr, 8);
+#if defined(BS_DIAG) && (BS_DIAG & 4)
+                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(B::xor_(addr, va[k]), amt); });   // DIAGNOSTIC
+#else
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
+#endif
                     } else {
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
                     }
@@ -573,6 +619,7 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     });
 
     d.reset_state(b);                  // (after the LLRs: row 0's LDS state aliases the staging slab)
+    d.prime_perm(b);
 
     // ---- iterations (decoder.rs:380-464): the codewords of the wave run in lockstep, a finished one is frozen ----
     uint64_t frozen_mask = ~valid_mask;

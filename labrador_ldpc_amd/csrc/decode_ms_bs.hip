@@ -14,12 +14,17 @@
 #include "decode_ms_bitslice.hpp"
 #include "hip_backend.hpp"
 
+#if defined(BS_DIAG) && !defined(BS_DIAG_BUILD)
+#error "BS_DIAG builds decode wrongly: only tools/bs_diag_build.sh may define it"
+#endif
+
 namespace ldpc {
 namespace bs {
 
 
-// waves per SIMD the kernel is compiled for: the rate-1/2 and rate-2/3 codes hold a group of codewords in <= 256 registers; the
-// rate-4/5 codes' state (39 edges: ~250 planes before any temporary) needs the whole file of one wave per SIMD
+// waves per SIMD the kernel is compiled for: two for every code (256 registers).  The rate-1/2 and rate-2/3 codes hold a group of
+// codewords in that; the rate-4/5 codes' state (39 edges: ~250 planes before any temporary) is put on the "register diet" of
+// decode_ms_bitslice.hpp to fit -- one wave per SIMD with everything in registers measured 23.4 against 33.3 M codewords/s (TM5120)
 template <int CODE> constexpr int waves_per_simd() { return 2; }
 
 constexpr int WS_HEADER_WORDS = 64;          // the queue head, on a 256-byte line of its own
