@@ -90,7 +90,10 @@ static_assert(TT_XOR3 == 0x96 && TT_MAJ == 0xE8 && TT_MUX == 0xCA && TT_OR3 == 0
 constexpr int ilog2c(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
 // ---- geometry of a code in the bit-sliced layout ----------------------------------------------------------------------
-template <int CODE>
+// HALF = -1: one wave decodes a group of codewords alone.  HALF = 0 / 1: the wave is one of TWO that share a group, each owning a run of
+// block columns with all their edges (the "split" kernel of the rate-4/5 codes, decode_ms_bitslice_split.hpp): everything below that
+// counts edges, exchanged edges or transmitted columns then counts the OWNED ones.
+template <int CODE, int HALF = -1>
 struct Geo {
     static constexpr Prototype P = *CODES[CODE].proto;
     static constexpr int M = CODES[CODE].m, N = CODES[CODE].n, NP = N + CODES[CODE].p;
@@ -107,9 +110,48 @@ struct Geo {
     // slot of block b inside its row (the arg-min identifier)
     static constexpr int slot_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += P.blk[i].row == P.blk[b].row; return s; }
     static constexpr bool local(int b) { return P.blk[b].kind == BLK_I && P.blk[b].val == 0; }
-    // ordinal of block b among the exchanged (pi_k) blocks
-    static constexpr int exch_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += local(i) ? 0 : 1; return s; }
+    // the split: the set of block columns of half 0 (bit c of SPLIT_MASK) that balances the two waves' work best -- an exchanged edge
+    // counted as 5/4 of a local one (its 16 ds_bpermute + v_alignbit), a block row with edges on both sides as the exchange and the
+    // merge it costs each wave; found by trying every subset (at most 2^11)
+    static constexpr int col_degree(int c) { int n = 0; for (int b = 0; b < NB; ++b) n += P.blk[b].col == c; return n; }
+    static constexpr int half_cost(unsigned mask, int h)
+    {
+        int cost = 0;
+        for (int b = 0; b < NB; ++b)
+            if ((int)((mask >> P.blk[b].col) & 1u) == (h == 0 ? 1 : 0)) cost += local(b) ? 120 : 150;
+        for (int r = 0; r < NROWS; ++r) {
+            bool in0 = false, in1 = false;
+            for (int b = 0; b < NB; ++b)
+                if (P.blk[b].row == r) { if ((mask >> P.blk[b].col) & 1u) in0 = true; else in1 = true; }
+            if (in0 && in1) cost += 200;
+        }
+        return cost;
+    }
+    static constexpr unsigned split_mask()
+    {
+        unsigned best = 1u;
+        int best_c = 1 << 30;
+        for (unsigned m = 1u; m + 1u < (1u << NCOLS); ++m) {
+            if (!(m & 1u)) continue;                                       // (column 0 in half 0: one of each mirrored pair)
+            const int c0 = half_cost(m, 0), c1 = half_cost(m, 1), c = c0 > c1 ? c0 : c1;
+            if (c < best_c) { best_c = c; best = m; }
+        }
+        return best;
+    }
+    static constexpr unsigned SPLIT_MASK = split_mask();
+    static constexpr bool in_half0(int c) { return (SPLIT_MASK >> c) & 1u; }
+    static constexpr bool SPLIT = HALF >= 0;
+    static constexpr bool owns_col(int c) { return HALF < 0 || in_half0(c) == (HALF == 0); }
+    static constexpr bool owns(int b) { return owns_col(P.blk[b].col); }
+    static constexpr bool row_in_half(int r, int h) { for (int b = 0; b < NB; ++b) if (P.blk[b].row == r && in_half0(P.blk[b].col) == (h == 0)) return true; return false; }
+    static constexpr bool has_row(int r) { return HALF < 0 || row_in_half(r, HALF); }                      // this wave has edges in block row r
+    static constexpr bool shared_row(int r) { return SPLIT && row_in_half(r, 0) && row_in_half(r, 1); }   // ... and so has the other
+    // ordinal of block b among the OWNED exchanged (pi_k) blocks
+    static constexpr int exch_of(int b) { int s = 0; for (int i = 0; i < b; ++i) s += (owns(i) && !local(i)) ? 1 : 0; return s; }
     static constexpr int NX = exch_of(NB);
+    // ordinal of block column c among the owned transmitted ones, and their number
+    static constexpr int llr_slot(int c) { int s = 0; for (int i = 0; i < c; ++i) s += (owns_col(i) && i < NTX) ? 1 : 0; return s; }
+    static constexpr int NTX_OWN = llr_slot(NCOLS);
     // the order in which an iteration uses the permutation-table entries (entry 2x = check -> variable alignment of exchanged edge x,
     // 2x + 1 = the way back): block column by block column, the variable side's edges, then the check side's
     struct PermOrder { int idx[2 * NB + 1]; int pos[2 * NB + 1]; };
@@ -120,7 +162,7 @@ struct Geo {
         for (int c = 0; c < NCOLS; ++c)
             for (int side = 0; side < 2; ++side)
                 for (int e = 0; e < NB; ++e)
-                    if (P.blk[e].col == c && !local(e)) o.idx[n++] = exch_of(e) * 2 + side;
+                    if (P.blk[e].col == c && owns(e) && !local(e)) o.idx[n++] = exch_of(e) * 2 + side;
         for (int i = 0; i < n; ++i) o.pos[o.idx[i]] = i;
         return o;
     }
@@ -128,26 +170,34 @@ struct Geo {
     static constexpr int perm_after(int idx) { return PERM_ORDER.idx[(PERM_ORDER.pos[idx] + 1) % (2 * NX)]; }
     // The rate-4/5 codes keep their LLR planes in a global workspace (one slot per resident wave, re-read from L2 / MALL in every
     // iteration, 20 KB per wave): in LDS they alone would take the 160 KB of a CU at two waves per SIMD.
-    static constexpr bool LLR_GLOBAL = P.n_blocks > 30;
-    static constexpr int LLR_WORDS = NTX * 8 * 64;                 // words of LLR planes per wave
+    static constexpr bool LLR_GLOBAL = !SPLIT && P.n_blocks > 30;
+    static constexpr int LLR_WORDS = NTX_OWN * 8 * 64;             // words of LLR planes per wave
     // Register diet of the rate-4/5 codes (39 edges: 218 planes of state before any temporary, against 256 registers at two waves
     // per SIMD): the hard decisions and the whole state of block row 0 -- three edges per iteration -- live in LDS, the lane
     // permutations are 16-bit entries.
-    static constexpr bool HARD_LDS = LLR_GLOBAL, ROW0_LDS = LLR_GLOBAL, PERM16 = LLR_GLOBAL;
+    static constexpr bool HARD_LDS = LLR_GLOBAL, ROW0_LDS = LLR_GLOBAL, PERM16 = P.n_blocks > 30;
     // ... and every state update and every use of the old row state is pinned to its place in the program (Decoder::pin): without
     // that the instruction selector's data-flow order keeps ~500 values live on these codes.  The smaller codes fit their
     // registers without the pins and run 6 % faster with the freedom (TM8192 16.9 against 15.9 M codewords/s).
-    static constexpr int PINNED = LLR_GLOBAL ? 2 : (P.n_blocks > 20 ? 1 : 0);       // 2: everything; 1: the state updates only (rate 2/3)
+#ifndef BS_SPLIT_PINNED
+#define BS_SPLIT_PINNED 0          // (measured: 0 -> 36.8, 1 -> 36.3, 2 -> 34.4 M codewords/s on TM5120 at 4 dB, profiles/r04_kbench/split_rate.txt)
+#endif
+    static constexpr int PINNED = LLR_GLOBAL ? 2 : SPLIT ? BS_SPLIT_PINNED : (P.n_blocks > 20 ? 1 : 0);       // 2: everything; 1: the state updates only (rate 2/3)
     static constexpr int ROW_OLD = 15 + ARG, ROW_NEW = 18 + ARG;               // planes of a row's old / running state
     // LDS: lane permutations of the exchanged blocks [NX][2 directions][64] (source lane address | rotate amount << 8; constant for
     // the kernel's lifetime), hard-decision words [NCOLS][64], row 0's state [ROW_OLD + ROW_NEW][64] (if ROW0_LDS), LLR planes
     // [NTX][8][64] (unless in the global workspace), a 2048-byte staging slab for the LLR transposition (aliases row 0's state,
     // which is initialised after the LLRs are in place)
-    static constexpr int LDS_PERM = 0, LDS_HARD = LDS_PERM + NX * 2 * 64 * (PERM16 ? 2 : 4), LDS_ROW0 = LDS_HARD + NCOLS * 256,
+    // Split mode: a wave's private area is [permutations | LLR planes]; the hard-decision words of the epilogue alias the LLR planes
+    // (dead by then) and the staging slab is the wave's exchange buffer, which lies behind both private areas (SplitLayout).
+    static constexpr int LDS_PERM = 0, LDS_PERM_END = LDS_PERM + NX * 2 * 64 * (PERM16 ? 2 : 4);
+    static constexpr int LDS_HARD = SPLIT ? LDS_PERM_END : LDS_PERM_END, LDS_ROW0 = SPLIT ? LDS_PERM_END : LDS_HARD + NCOLS * 256,
                          LDS_LLR = LDS_ROW0 + (ROW0_LDS ? (ROW_OLD + ROW_NEW) * 256 : 0),
-                         LDS_STAGE = ROW0_LDS ? LDS_ROW0 : LDS_LLR + (LLR_GLOBAL ? 0 : LLR_WORDS * 4),
-                         LDS_BYTES = ROW0_LDS ? LDS_LLR + (LLR_GLOBAL ? 0 : LLR_WORDS * 4) : LDS_STAGE + 2048;
+                         LDS_PRIVATE = LDS_LLR + (LLR_GLOBAL ? 0 : LLR_WORDS * 4),
+                         LDS_STAGE = ROW0_LDS ? LDS_ROW0 : LDS_PRIVATE,        // (split mode: Decoder::stage_base overrides it)
+                         LDS_BYTES = ROW0_LDS ? LDS_PRIVATE : LDS_STAGE + 2048;
     static_assert(!ROW0_LDS || (ROW_OLD + ROW_NEW) * 256 >= 2048);
+    static_assert(!SPLIT || NCOLS * 256 <= LLR_WORDS * 4, "the epilogue's hard-decision words alias the LLR planes");
 };
 
 // ---- arithmetic on bit planes -------------------------------------------------------------------------------------------
@@ -195,10 +245,10 @@ struct Arith {
 };
 
 // ---- the decoder of one group of G codewords, executed by one wave --------------------------------------------------------
-template <int CODE, class B>
+template <int CODE, class B, int HALF = -1>
 struct Decoder {
     using V = typename B::V;
-    using GEO = Geo<CODE>;
+    using GEO = Geo<CODE, HALF>;
     using A = Arith<B>;
     static constexpr int M = GEO::M, L = GEO::L, W = GEO::W, G = GEO::G, NB = GEO::NB, NROWS = GEO::NROWS, NCOLS = GEO::NCOLS, NTX = GEO::NTX;
     static constexpr int ARG = GEO::ARG;
@@ -226,16 +276,20 @@ struct Decoder {
         // decoder.rs:374: the working area is zeroed, so before iteration 0 min1 = min2 = 0, every v = 0, every sign product +
         sfor<0, NROWS>([&](auto R_) {
             constexpr int r = decltype(R_)::value;
-            sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
-            S[r] = B::c(0);
-            sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
-            spill_old<r>(b);
+            if constexpr (GEO::has_row(r)) {
+                sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
+                S[r] = B::c(0);
+                sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
+                spill_old<r>(b);
+            }
         });
-        sfor<0, NB>([&](auto E_) { constexpr int e = decltype(E_)::value; sv[e] = B::c(0); nz[e] = B::c(0); });
+        sfor<0, NB>([&](auto E_) { constexpr int e = decltype(E_)::value; if constexpr (GEO::owns(e)) { sv[e] = B::c(0); nz[e] = B::c(0); } });
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
-            if constexpr (GEO::HARD_LDS) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), B::c(0));
-            else hard[c] = B::c(0);
+            if constexpr (GEO::owns_col(c)) {
+                if constexpr (GEO::HARD_LDS) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), B::c(0));
+                else hard[c] = B::c(0);
+            }
         });
     }
 
@@ -391,7 +445,7 @@ struct Decoder {
     {
         sfor<0, NB>([&](auto E_) {
             constexpr int e = decltype(E_)::value;
-            if constexpr (!GEO::local(e)) {
+            if constexpr (GEO::owns(e) && !GEO::local(e)) {
                 V addr, amt;
                 perm_c2v<GEO::P.blk[e].val>(addr, amt);
                 put_perm_entry<GEO::exch_of(e) * 2 + 0>(b, B::or_(addr, B::shl(B::and_(amt, B::c(31)), 8)));
@@ -405,16 +459,30 @@ struct Decoder {
     // `frozen`: all ones in the lanes of codewords that are finished (their hard decisions stay as they are)
     BS_FN V iteration(B &b, V frozen, const uint32_t *ws)
     {
+        begin_iteration(b);
+        columns(b, frozen, ws);
+        return finish_iteration(b);
+    }
+    // the running state of every block row this wave has edges in: two keys of +127, no sign, no parity
+    BS_FN void begin_iteration(B &b)
+    {
         sfor<0, NROWS>([&](auto R_) {
             constexpr int r = decltype(R_)::value;
-            W1[r][0] = B::c(0); W2[r][0] = B::c(0);                                  // key of +127 = 254 (decoder.rs:414-415: maxval)
-            sfor<1, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = B::c(0xFFFFFFFFu); W2[r][k] = B::c(0xFFFFFFFFu); });
-            Sn[r] = B::c(0); Pn[r] = B::c(0);
-            sfor<0, ARG>([&](auto K_) { argn[r][decltype(K_)::value] = B::c(0); });
-            spill_new<r>(b);
+            if constexpr (GEO::has_row(r)) {
+                W1[r][0] = B::c(0); W2[r][0] = B::c(0);                              // key of +127 = 254 (decoder.rs:414-415: maxval)
+                sfor<1, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = B::c(0xFFFFFFFFu); W2[r][k] = B::c(0xFFFFFFFFu); });
+                Sn[r] = B::c(0); Pn[r] = B::c(0);
+                sfor<0, ARG>([&](auto K_) { argn[r][decltype(K_)::value] = B::c(0); });
+                spill_new<r>(b);
+            }
         });
+    }
+    // the owned block columns: variable side, then check side, of each
+    BS_FN void columns(B &b, V frozen, const uint32_t *ws)
+    {
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
+            if constexpr (GEO::owns_col(c)) {
             B::fence();            // keep the compiler from hoisting the next column's loads over this one's arithmetic (register pressure)
             // ---- variable side: marginal of block column c (decoder.rs:382-383, :408) ----
             V va[8];
@@ -428,7 +496,7 @@ struct Decoder {
 #else
                     if constexpr (GEO::LLR_GLOBAL) va[k] = b.gload32(ws, B::add(at, B::c((c * 8 + k) * 256)), B::c(0xFFFFFFFFu));
 #endif
-                    else va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (c * 8 + k) * 256)));
+                    else va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)));
                 });
             } else {
                 sfor<0, 8>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
@@ -519,11 +587,16 @@ struct Decoder {
                     B::fence();
                 }
             });
+            }
         });
-        // ---- the new row state becomes the old one; minima back to magnitudes: (key + 1) >> 1 = (key >> 1) + (key & 1) ----
+    }
+    // ---- the new row state becomes the old one; minima back to magnitudes: (key + 1) >> 1 = (key >> 1) + (key & 1) ----
+    BS_FN V finish_iteration(B &b)
+    {
         V fail = B::c(0);
         sfor<0, NROWS>([&](auto R_) {
             constexpr int r = decltype(R_)::value;
+            if constexpr (GEO::has_row(r)) {
             auto to_mag = [&](const V (&key)[8], V (&mag)[7]) {
                 V c = key[0];
                 sfor<0, 7>([&](auto K_) {
@@ -539,6 +612,7 @@ struct Decoder {
             sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[r][k] = argn[r][k]; });
             fail = B::or_(fail, Pn[r]);
             spill_old<r>(b);
+            }
         });
         return fail;                                                                  // non-zero bits = unsatisfied checks (:453)
     }

@@ -1,0 +1,274 @@
+// decode_ms_bitslice_split.hpp -- the bit-sliced i8 min-sum decoder of decode_ms_bitslice.hpp with a group of codewords shared by TWO
+// waves (decode_ms::<i8>, /root/reference/src/decoder.rs:42-50, :347-475), for the rate-4/5 codes (TM1280, TM5120).
+//
+// Why.  A rate-4/5 codeword group has 39 edges: 218 planes of state before any temporary.  One wave holds that in 256 registers only
+// on a diet (decode_ms_bitslice.hpp: LLR planes in a global workspace re-read in every iteration, block row 0 and the hard decisions
+// in LDS, every use pinned in place): 164 VALU instructions per edge against 135 on the rate-1/2 codes, 12-22 x the algorithmic bytes at
+// the L2 boundary.  Here wave 0 owns a set of block columns (Geo::SPLIT_MASK) with all their edges and wave 1 the rest (19 + 20 edges, five
+// transmitted columns each): a wave's state is ~120 planes, its LLR planes fit LDS (10 KB), nothing is pinned or spilled, and the
+// launch moves its algorithmic bytes.
+//
+// What the two waves exchange.  An edge's message u needs its block row's state -- the two smallest |v| of the row, the sign product,
+// the arg-min slot -- over ALL the row's edges, and a row's edges lie in both halves (block rows 1 and 2; row 0's three edges are all
+// wave 1's).  Each wave accumulates the row state over ITS edges; once per iteration and shared row the partial states cross through a
+// 24-plane LDS buffer per wave and each wave merges the other's into its own (the two smallest keys of a union are
+// min(a1, b1) and min(max(a1, b1), min(a2, b2)); signs and parities XOR; the arg-min slot follows the smaller min1, wave 0's on a
+// tie, so both waves end with the same state).  Four workgroup barriers per iteration (two waves: they arrive together).
+//
+// The stages are separate member functions so that tests/c/bitslice_emu.cpp can run the two halves of a group alternately on the CPU.
+#pragma once
+
+#include "decode_ms_bitslice.hpp"
+
+namespace ldpc {
+namespace bs {
+
+// LDS of a split workgroup: [wave 0: permutations | LLR planes] [wave 1: the same] [exchange buffer of wave 0] [of wave 1]
+template <int CODE>
+struct SplitLayout {
+    using G0 = Geo<CODE, 0>;
+    using G1 = Geo<CODE, 1>;
+    static constexpr int XEXTRA = 18 + G0::ARG;                               // W1 8, W2 8, Sn, Pn, argn ARG; then the parity of the unshared rows
+    static constexpr int XPLANES = XEXTRA + 1;
+    static constexpr int XBYTES = XPLANES * 256;
+    static_assert(XBYTES >= 2048, "the exchange buffer doubles as the staging slab of the LLR transposition");
+    static constexpr int PRIV0 = 0, PRIV1 = G0::LDS_PRIVATE, XBUF0 = PRIV1 + G1::LDS_PRIVATE, XBUF1 = XBUF0 + XBYTES, BYTES = XBUF1 + XBYTES;
+    template <int H> static constexpr int priv() { return H == 0 ? PRIV0 : PRIV1; }
+    template <int H> static constexpr int own_x() { return (H == 0 ? XBUF0 : XBUF1) - priv<H>(); }      // relative to the wave's private base
+    template <int H> static constexpr int other_x() { return (H == 0 ? XBUF1 : XBUF0) - priv<H>(); }
+};
+
+template <int CODE, class B, int HALF>
+struct SplitGroup {
+    using V = typename B::V;
+    using GEO = Geo<CODE, HALF>;
+    using LAY = SplitLayout<CODE>;
+    using A = Arith<B>;
+    static constexpr int M = GEO::M, N = GEO::N, L = GEO::L, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS, NROWS = GEO::NROWS, Q = GEO::Q,
+                         ARG = GEO::ARG;
+    static constexpr int XO = LAY::template own_x<HALF>(), XT = LAY::template other_x<HALF>();
+    template <int TT> static BS_FN V op3(V a, V b, V c) { return B::template bitop3<TT>(a, b, c); }
+
+    Decoder<CODE, B, HALF> d;
+    V lane, cw, lw, frame, valid, iters_v, ok_v, extra_fail;
+    uint64_t valid_mask = 0, frozen_mask = 0;
+    const int8_t *llrs = nullptr;
+    uint8_t *output = nullptr;
+    uint32_t *iters = nullptr;
+    uint8_t *success = nullptr;
+
+    // once per kernel and wave: the lane permutation tables of the owned exchanged edges
+    BS_FN void init(B &b) { d.init_lane(b); d.init_perm_tables(b); }
+
+    // ---- LLRs of the owned transmitted columns -> bit planes in LDS; state zeroed ----
+    BS_FN void prologue(B &b, const int8_t *llrs_all, uint8_t *output_all, uint32_t *iters_all, uint8_t *success_all, uint32_t batch,
+                        uint32_t maxiters, uint32_t group)
+    {
+        d.init_lane(b);
+        lane = d.lane;
+        cw = B::shr(lane, ilog2c(W));
+        lw = B::and_(lane, B::c(W - 1));
+        llrs = llrs_all + (size_t)group * G * GEO::N;
+        output = output_all + (size_t)group * G * GEO::OUT_LEN;
+        iters = iters_all + (size_t)group * G;
+        success = success_all + (size_t)group * G;
+        frame = cw;
+        valid = B::less_u(B::add(B::c(group * (uint32_t)G), cw), B::c(batch));
+        valid_mask = b.ballot(valid);
+        sfor<0, NTX>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            if constexpr (GEO::owns_col(c)) {
+                const V src = B::add(B::mul_u(frame, (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));
+                sfor<0, 8>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i)), valid), valid);
+                    b.lds_write32(B::add(B::shl(lane, 5), B::c(XO + 4 * i)), w);
+                });
+                const V base = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), B::add(d.ll, B::c(XO)));
+                V X[8];
+                sfor<0, 8>([&](auto D_) {
+                    constexpr int dd = decltype(D_)::value;
+                    V x = b.lds_read_u8(B::add(base, B::c(L * dd)));
+                    x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (8 + dd)))), 8));
+                    x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (16 + dd)))), 16));
+                    x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (24 + dd)))), 24));
+                    X[dd] = x;
+                });
+                auto stage = [&](auto S_, uint32_t mask) {
+                    constexpr int s = decltype(S_)::value;
+                    sfor<0, 8>([&](auto D_) {
+                        constexpr int dd = decltype(D_)::value;
+                        if constexpr ((dd & s) == 0) {
+                            const V t = B::and_(B::xor_(B::shr(X[dd], s), X[dd + s]), B::c(mask));
+                            X[dd + s] = B::xor_(X[dd + s], t);
+                            X[dd] = B::xor_(X[dd], B::shl(t, s));
+                        }
+                    });
+                };
+                stage(IC<4>{}, 0x0F0F0F0Fu);
+                stage(IC<2>{}, 0x33333333u);
+                stage(IC<1>{}, 0x55555555u);
+                sfor<0, 8>([&](auto K_) {
+                    constexpr int k = decltype(K_)::value;
+                    b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)), X[k]);
+                });
+            }
+        });
+        d.reset_state(b);
+        d.prime_perm(b);
+        frozen_mask = ~valid_mask;
+        iters_v = B::c(maxiters);
+        ok_v = B::c(0);
+        extra_fail = B::c(0);
+    }
+
+    BS_FN bool running() const { return frozen_mask != ~0ull; }
+
+    // ---- stage 1 of an iteration: the owned block columns ----
+    BS_FN void stage_columns(B &b)
+    {
+        const V frozen = b.plane_of(frozen_mask);
+        d.begin_iteration(b);
+        d.columns(b, frozen, nullptr);
+    }
+    static BS_FN V xaddr(V lane, int base, int plane) { return B::add(B::shl(lane, 2), B::c(base + plane * 256)); }
+
+    // ---- stage 2 (per shared row): this wave's partial state of block row R into its exchange buffer.  With the FIRST shared row
+    // goes the parity of the rows only this wave has (the other needs it for the verdict). ----
+    template <int R>
+    BS_FN void stage_write(B &b)
+    {
+        static_assert(GEO::shared_row(R));
+        sfor<0, 8>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            b.lds_write32(xaddr(lane, XO, k), d.W1[R][k]);
+            b.lds_write32(xaddr(lane, XO, 8 + k), d.W2[R][k]);
+        });
+        b.lds_write32(xaddr(lane, XO, 16), d.Sn[R]);
+        b.lds_write32(xaddr(lane, XO, 17), d.Pn[R]);
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(xaddr(lane, XO, 18 + k), d.argn[R][k]); });
+        if constexpr (R == first_shared()) {
+            V own = B::c(0);
+            sfor<0, NROWS>([&](auto R2_) {
+                constexpr int r2 = decltype(R2_)::value;
+                if constexpr (GEO::has_row(r2) && !GEO::shared_row(r2)) own = B::or_(own, d.Pn[r2]);
+            });
+            b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), own);
+        }
+    }
+    static constexpr int first_shared() { for (int r = 0; r < NROWS; ++r) if (GEO::shared_row(r)) return r; return -1; }
+
+    // ---- stage 3 (per shared row): the other wave's partial state of block row R merged into this wave's ----
+    template <int R>
+    BS_FN void stage_merge(B &b)
+    {
+        static_assert(GEO::shared_row(R));
+        V o1[8], o2[8], oarg[ARG > 0 ? ARG : 1];
+        sfor<0, 8>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            o1[k] = b.lds_read32(xaddr(lane, XT, k));
+            o2[k] = b.lds_read32(xaddr(lane, XT, 8 + k));
+        });
+        const V os = b.lds_read32(xaddr(lane, XT, 16)), op = b.lds_read32(xaddr(lane, XT, 17));
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; oarg[k] = b.lds_read32(xaddr(lane, XT, 18 + k)); });
+        if constexpr (R == first_shared()) extra_fail = b.lds_read32(xaddr(lane, XT, LAY::XEXTRA));
+        // take the other's min1 where it is smaller -- wave 0's wins a tie, in both waves
+        V take;
+        if constexpr (HALF == 0) take = A::less_than(o1, d.W1[R]);                  // other (wave 1) strictly smaller
+        else take = B::not_(A::less_than(d.W1[R], o1));                             // mine (wave 1) not strictly smaller
+        V hi[8], lo[8];
+        const V lt2 = A::less_than(o2, d.W2[R]);
+        sfor<0, 8>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            hi[k] = op3<TT_MUX>(take, d.W1[R][k], o1[k]);                            // the larger of the two min1
+            d.W1[R][k] = op3<TT_MUX>(take, o1[k], d.W1[R][k]);
+            lo[k] = op3<TT_MUX>(lt2, o2[k], d.W2[R][k]);                             // the smaller of the two min2
+        });
+        const V lt3 = A::less_than(hi, lo);
+        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; d.W2[R][k] = op3<TT_MUX>(lt3, hi[k], lo[k]); });
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = op3<TT_MUX>(take, oarg[k], d.argn[R][k]); });
+        d.Sn[R] = B::xor_(d.Sn[R], os);
+        d.Pn[R] = B::xor_(d.Pn[R], op);
+    }
+
+    // ---- stage 4: new state -> old state, the verdict of iteration `it` (the same in both waves) ----
+    BS_FN void stage_finish(B &b, uint32_t it)
+    {
+        const V fail = B::or_(d.finish_iteration(b), extra_fail);
+        const uint64_t unsat_lanes = b.ballot(fail);
+        uint64_t unsat = 0;
+        if constexpr (W == 64) unsat = unsat_lanes ? ~0ull : 0ull;
+        else {
+            constexpr uint64_t gm = (1ull << W) - 1;
+            for (int g = 0; g < G; ++g)
+                if ((unsat_lanes >> (g * W)) & gm) unsat |= gm << (g * W);
+        }
+        const uint64_t newly = ~frozen_mask & ~unsat;
+        const V nw = b.plane_of(newly);
+        iters_v = op3<TT_MUX>(nw, B::c(it), iters_v);
+        ok_v = B::or_(ok_v, B::and_(nw, B::c(1)));
+        frozen_mask |= newly;
+    }
+
+    // ---- hard decisions of the owned columns, MSB first; iterations and success by wave 0 ----
+    BS_FN void epilogue(B &b)
+    {
+        sfor<0, NCOLS>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            if constexpr (GEO::owns_col(c)) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c_slot(c) * 256)), d.hard[c]);
+        });
+        const V b0 = B::shl(d.ll, 5 - ilog2c(L));
+        const V qbase = B::shl(B::add(d.cwbase, B::shl(d.q, ilog2c(L))), 2);
+        sfor<0, NCOLS>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            if constexpr (GEO::owns_col(c)) {
+                V out = B::c(0);
+                sfor<0, L>([&](auto LL_) {
+                    constexpr int l2 = decltype(LL_)::value;
+                    const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(GEO::LDS_HARD + c_slot(c) * 256 + 4 * l2))), b0);
+                    sfor<0, 32 / L>([&](auto K_) {
+                        constexpr int k = decltype(K_)::value;
+                        constexpr int t = l2 + L * k;
+                        constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
+                        out = B::or_(out, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
+                    });
+                });
+                b.gstore32(output, B::add(B::mul_u(frame, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw, 2))), out, valid);
+            }
+        });
+        if constexpr (HALF == 0) {
+            const V first = B::and_(valid, B::eq(lw, B::c(0)));
+            b.gstore32(iters, B::shl(frame, 2), iters_v, first);
+            b.gstore8(success, frame, ok_v, first);
+        }
+    }
+    // ordinal of block column c among the owned ones (the epilogue's hard-decision words alias the LLR planes)
+    static constexpr int c_slot(int c) { int s = 0; for (int i = 0; i < c; ++i) s += GEO::owns_col(i) ? 1 : 0; return s; }
+};
+
+// One wave's program for a group: the HIP kernel calls it with a workgroup barrier for SYNC, every wave of the pair with its HALF.
+template <int CODE, class B, int HALF, class SYNC>
+BS_FN void decode_group_split(B &b, SplitGroup<CODE, B, HALF> &g, const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, uint32_t batch,
+                              uint32_t maxiters, uint32_t group, SYNC sync)
+{
+    using GEO = Geo<CODE, HALF>;
+    g.prologue(b, llrs, out, iters, ok, batch, maxiters, group);
+    for (uint32_t it = 0; it < maxiters && g.running(); ++it) {
+        g.stage_columns(b);
+        sfor<0, GEO::NROWS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            if constexpr (GEO::shared_row(r)) {
+                sync();                        // the other wave has read what this buffer held
+                g.template stage_write<r>(b);
+                sync();                        // both partial states are in place
+                g.template stage_merge<r>(b);
+            }
+        });
+        g.stage_finish(b, it);
+    }
+    sync();                                    // (the epilogue's hard-decision words alias nothing the other wave reads, but the next
+    g.epilogue(b);                             //  group's staging slab is this buffer)
+}
+
+}  // namespace bs
+}  // namespace ldpc

@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "decode_ms_bitslice.hpp"
+#include "decode_ms_bitslice_split.hpp"
 #include "hip_backend.hpp"
 
 #if defined(BS_DIAG) && !defined(BS_DIAG_BUILD)
@@ -55,6 +56,42 @@ decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ outpu
     }
 }
 
+// ---- the rate-4/5 codes: a group of codewords shared by the two waves of a workgroup (decode_ms_bitslice_split.hpp).  One group per
+// workgroup: the hardware dispatcher is the work queue, as for the rate-1/2 and rate-2/3 kernel above. ----
+template <int CODE, int HALF>
+__device__ __forceinline__ void split_wave(char *lds, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, uint32_t batch,
+                                           uint32_t maxiters, uint32_t ngroups)
+{
+    HipBackend b{lds + SplitLayout<CODE>::template priv<HALF>()};
+    SplitGroup<CODE, HipBackend, HALF> g;
+    g.init(b);
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
+        decode_group_split<CODE, HipBackend, HALF>(b, g, llrs, output, iters, success, batch, maxiters, grp, [] { __syncthreads(); });
+}
+
+template <int CODE>
+__global__ void __launch_bounds__(128, 2)
+decode_ms_bs_split_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters, uint8_t *__restrict__ success,
+                          uint32_t batch, uint32_t maxiters, uint32_t ngroups)
+{
+    __shared__ __attribute__((aligned(16))) char lds[SplitLayout<CODE>::BYTES];
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) split_wave<CODE, 0>(lds, llrs, output, iters, success, batch, maxiters, ngroups);
+    else split_wave<CODE, 1>(lds, llrs, output, iters, success, batch, maxiters, ngroups);
+}
+
+template <int CODE>
+hipError_t launch_split(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
+{
+    constexpr int G = Geo<CODE>::G;
+    if (batch == 0) return hipSuccess;
+    if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const size_t groups = (batch + G - 1) / G;
+    const size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
+    hipLaunchKernelGGL((decode_ms_bs_split_kernel<CODE>), dim3((unsigned)grid), dim3(128), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
+                       (uint32_t)groups);
+    return hipGetLastError();
+}
+
 template <int CODE>
 hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
 {
@@ -94,6 +131,17 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
 }
 
 }  // namespace bs
+
+// the rate-4/5 codes through the two-waves-per-group kernel; hipErrorInvalidConfiguration for every other code
+hipError_t launch_decode_ms_bitsliced_split(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                            uint32_t maxiters, hipStream_t stream)
+{
+    switch (code) {
+        case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
 
 // i8 LLRs through the bit-sliced kernel; hipErrorInvalidConfiguration for the codes it is not built for (the TC codes: their
 // circulants are not quarter-wise rotations).  llrs 4-byte aligned, output 4-byte aligned.

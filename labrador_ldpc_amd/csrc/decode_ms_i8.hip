@@ -22,24 +22,31 @@ namespace ldpc {
 // faster on those (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
                                       uint32_t maxiters, hipStream_t stream);
+hipError_t launch_decode_ms_bitsliced_split(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                            uint32_t maxiters, hipStream_t stream);
 constexpr int VARIANT_BITSLICE = 64;
+// The rate-4/5 codes (TM1280, TM5120) have two bit-sliced kernels: a codeword group shared by the two waves of a workgroup
+// (decode_ms_bitslice_split.hpp) -- what `variant` 64 and the default dispatch mean for them -- and, `variant` 128, round 4's first form:
+// one wave per group with its LLR planes in a stream-ordered global workspace (kept for the A/B: profiles/r04_kbench/split_rate.txt).
+constexpr int VARIANT_BITSLICE_ONE_WAVE = 128;
+static hipError_t launch_bitsliced_default_form(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                                uint32_t maxiters, hipStream_t stream)
+{
+    if (code == TM1280 || code == TM5120) return launch_decode_ms_bitsliced_split(code, llrs, output, iters, success, batch, maxiters, stream);
+    return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
+}
 // groups of 64 / (M/32) codewords from which the bit-sliced kernel is faster per call (tools/bs_crossover.py,
-// profiles/r04_kbench/bs_crossover.txt: TM8192 and TM6144 cross at 1024 groups, TM2048 and TM5120 at 2048, TM1536 at 8192, TM1280 --
-// sixteen codewords of a wave in lockstep -- only beyond 16 384)
+// profiles/r04_kbench/bs_crossover.txt: TM8192 and TM6144 cross at 1024 groups, TM2048 at 2048, TM1536 at 8192; the rate-4/5 codes'
+// two-wave kernel -- twice the waves per group -- crosses at 768 (TM5120) and 2048 (TM1280) groups: profiles/r04_kbench/split_rate.txt)
 constexpr size_t bitslice_min_batch(int code)
 {
-    constexpr size_t groups[NUM_CODES] = {0, 0, 0, 32768, 8192, 2048, 2048, 1024, 1024};
+    constexpr size_t groups[NUM_CODES] = {0, 0, 0, 2048, 8192, 2048, 768, 1024, 1024};
     return code >= TM1280 && code <= TM8192 ? groups[code] * (size_t)(64 / (CODES[code].m / 32)) : ~(size_t)0;
 }
 static bool bitslice_default(int code, const int8_t *llrs, size_t batch, hipStream_t stream)
 {
-    if (batch < bitslice_min_batch(code) || (uintptr_t)llrs % 4) return false;
-    if (code == TM1280 || code == TM5120) {        // (these allocate their LLR workspace stream-ordered: not inside a graph capture)
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (stream == hipStreamPerThread || (stream != nullptr && (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone)))
-            return false;
-    }
-    return true;
+    (void)stream;                                  // (no kernel of the default form allocates anything: graph capture is fine)
+    return batch >= bitslice_min_batch(code) && (uintptr_t)llrs % 4 == 0;
 }
 
 template <>
@@ -50,13 +57,14 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
     LDPC_SPLIT_VARIANT();
     if (variant == VARIANT_BITSLICE) {
         if ((uintptr_t)llrs % 4) return hipErrorInvalidConfiguration;        // (its loads are dwords)
+        return launch_bitsliced_default_form(code, llrs, output, iters, success, batch, maxiters, stream);
+    }
+    if (variant == VARIANT_BITSLICE_ONE_WAVE) {
+        if ((uintptr_t)llrs % 4 || (code != TM1280 && code != TM5120)) return hipErrorInvalidConfiguration;
         return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
     }
-    if (variant == 0 && lflags == 0 && bitslice_default(code, llrs, batch, stream)) {
-        const hipError_t e = launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
-        if (e != hipErrorOutOfMemory && e != hipErrorNotSupported) return e;
-        (void)hipGetLastError();             // no stream-ordered workspace on this device / out of memory: the f32-pipe kernel needs none
-    }
+    if (variant == 0 && lflags == 0 && bitslice_default(code, llrs, batch, stream))
+        return launch_bitsliced_default_form(code, llrs, output, iters, success, batch, maxiters, stream);
     // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
         if (code == TM8192) return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);

@@ -6,10 +6,12 @@
 //   g++ -O1 -std=c++20 -shared -fPIC -DEMU_CODE=TM8192 -Ilabrador_ldpc_amd/csrc tests/c/bitslice_emu.cpp -o build/libbitslice_emu_TM8192.so
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #define BS_FN inline
 #include "decode_ms_bitslice.hpp"
+#include "decode_ms_bitslice_split.hpp"
 #include "decode_bf_bitslice.hpp"
 
 namespace {
@@ -20,8 +22,16 @@ struct Vec {
 
 struct EmuBackend {
     using V = Vec;
-    std::vector<uint8_t> lds;
-    explicit EmuBackend(size_t lds_bytes) : lds(lds_bytes, 0xA5) {}
+    // the workgroup's LDS (bounds-checked) and this wave's base in it: the two waves of a split group share one store
+    std::shared_ptr<std::vector<uint8_t>> store;
+    size_t base = 0;
+    explicit EmuBackend(size_t lds_bytes) : store(std::make_shared<std::vector<uint8_t>>(lds_bytes, 0xA5)) {}
+    EmuBackend(std::shared_ptr<std::vector<uint8_t>> shared, size_t base_) : store(std::move(shared)), base(base_) {}
+    struct Lds {
+        std::vector<uint8_t> *v; size_t base;
+        uint8_t &at(size_t a) const { return v->at(base + a); }
+    };
+    Lds lds_() const { return Lds{store.get(), base}; }
 
     template <class F> static V map1(const V &a, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i]); return r; }
     template <class F> static V map2(const V &a, const V &b, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i], b.l[i]); return r; }
@@ -59,12 +69,12 @@ struct EmuBackend {
     static V less_u(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x < y ? 0xFFFFFFFFu : 0u; }); }
     static V eq(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x == y ? 0xFFFFFFFFu : 0u; }); }
     V bperm(const V &addr, const V &x) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = x.l[(addr.l[i] >> 2) & 63]; return r; }
-    V lds_read32(const V &addr) const { V r; for (int i = 0; i < 64; ++i) std::memcpy(&r.l[i], &lds.at(addr.l[i]), 4), (void)lds.at(addr.l[i] + 3); return r; }
-    void lds_write32(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { (void)lds.at(addr.l[i] + 3); std::memcpy(&lds.at(addr.l[i]), &v.l[i], 4); } }
-    V lds_read_u16(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds.at(addr.l[i]) | (uint32_t)lds.at(addr.l[i] + 1) << 8; return r; }
-    void lds_write16(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { lds.at(addr.l[i]) = (uint8_t)v.l[i]; lds.at(addr.l[i] + 1) = (uint8_t)(v.l[i] >> 8); } }
-    void lds_write32_if(const V &addr, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) { (void)lds.at(addr.l[i] + 3); std::memcpy(&lds.at(addr.l[i]), &v.l[i], 4); } }
-    V lds_read_u8(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds.at(addr.l[i]); return r; }
+    V lds_read32(const V &addr) const { V r; for (int i = 0; i < 64; ++i) std::memcpy(&r.l[i], &lds_().at(addr.l[i]), 4), (void)lds_().at(addr.l[i] + 3); return r; }
+    void lds_write32(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { (void)lds_().at(addr.l[i] + 3); std::memcpy(&lds_().at(addr.l[i]), &v.l[i], 4); } }
+    V lds_read_u16(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds_().at(addr.l[i]) | (uint32_t)lds_().at(addr.l[i] + 1) << 8; return r; }
+    void lds_write16(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { lds_().at(addr.l[i]) = (uint8_t)v.l[i]; lds_().at(addr.l[i] + 1) = (uint8_t)(v.l[i] >> 8); } }
+    void lds_write32_if(const V &addr, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) { (void)lds_().at(addr.l[i] + 3); std::memcpy(&lds_().at(addr.l[i]), &v.l[i], 4); } }
+    V lds_read_u8(const V &addr) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = lds_().at(addr.l[i]); return r; }
     static V gload32(const void *p, const V &off, const V &pred)
     {
         V r;
@@ -91,6 +101,41 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
     return 0;
 }
 
+// the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp): the two halves of a group run stage by stage,
+// alternately, on one shared LDS store -- the order the workgroup barriers enforce on the GPU
+template <int CODE>
+int run_split(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    using namespace ldpc::bs;
+    using LAY = SplitLayout<CODE>;
+    using GEO = Geo<CODE, 0>;
+    const size_t groups = (batch + GEO::G - 1) / GEO::G;
+    for (size_t g = 0; g < groups; ++g) {
+        auto store = std::make_shared<std::vector<uint8_t>>(LAY::BYTES, 0xA5);
+        EmuBackend b0(store, LAY::PRIV0), b1(store, LAY::PRIV1);
+        SplitGroup<CODE, EmuBackend, 0> w0;
+        SplitGroup<CODE, EmuBackend, 1> w1;
+        w0.init(b0); w1.init(b1);
+        w0.prologue(b0, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
+        w1.prologue(b1, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
+        for (uint32_t it = 0; it < maxiters && w0.running(); ++it) {
+            if (w0.running() != w1.running()) return 2;                  // the two waves must agree on every verdict
+            w0.stage_columns(b0); w1.stage_columns(b1);
+            sfor<0, GEO::NROWS>([&](auto R_) {
+                constexpr int r = decltype(R_)::value;
+                if constexpr (GEO::shared_row(r)) {
+                    w0.template stage_write<r>(b0); w1.template stage_write<r>(b1);
+                    w0.template stage_merge<r>(b0); w1.template stage_merge<r>(b1);
+                }
+            });
+            w0.stage_finish(b0, it); w1.stage_finish(b1, it);
+            if (w0.frozen_mask != w1.frozen_mask) return 3;
+        }
+        w0.epilogue(b0); w1.epilogue(b1);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // One code per shared object (-DEMU_CODE=TM8192 ...): the six instantiations compile in parallel (tests/test_bitslice_emu.py).
@@ -111,6 +156,11 @@ extern "C" int bs_emu_decode_bf(const uint8_t *input, uint8_t *out, uint32_t *it
         ldpc::bs::bf_decode_group<ldpc::EMU_CODE, EmuBackend>(b, input, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
     }
     return 0;
+}
+extern "C" int bs_emu_decode_split(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    if constexpr (ldpc::bs::Geo<ldpc::EMU_CODE>::LLR_GLOBAL) return run_split<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+    else return -1;                                                     // rate 4/5 only
 }
 extern "C" int bs_emu_group(void) { return ldpc::bs::Geo<ldpc::EMU_CODE>::G; }
 extern "C" int bs_emu_code(void) { return ldpc::EMU_CODE; }

@@ -81,10 +81,16 @@ def test_roofline_of_prints_null_valu_issue_for_an_unprofiled_operating_point(tm
     roof, valu = b.roofline_of(tm2048, "TM2048", "i8", 0, 524288, 61.2, 25.0, build, 2.0, 25)
     assert valu is None and "no profile of TM2048_i8_2dB_25it" in roof["valu_issue_note"]
     assert roof["traffic"] == 3.1e8 * 4 and "TM2048_i8_4dB_25it" in roof["traffic_source"]      # bytes per frame: any operating point
-    # the rate-4/5 bit-sliced kernel re-reads its LLR planes every iteration: ITS traffic belongs to one operating point too
+    # the rate-4/5 codes' default: two waves per codeword group, LLR planes in LDS -- bytes per frame like every other kernel
     roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 0, 524288, 17.0, 8.4, build, 4.0, 25)
-    assert roof["kernel"] == "decode_ms_bs_kernel" and roof["traffic"] == 8.5e9 * 4 and "Infinity Cache" in roof["traffic_source"] and valu
+    assert roof["kernel"] == "decode_ms_bs_split_kernel" and roof["traffic"] == 8.5e9 * 4 and "Infinity Cache" not in roof["traffic_source"] and valu
     roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 0, 524288, 37.6, 25.0, build, 2.0, 25)
+    assert roof["traffic"] == 8.5e9 * 4 and valu is None
+    # `variant` 128, one wave per group, re-reads its LLR planes from a global workspace every iteration: ITS traffic belongs to one
+    # operating point
+    roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 128, 524288, 17.0, 8.4, build, 4.0, 25)
+    assert roof["kernel"] == "decode_ms_bs_kernel" and roof["traffic"] == 8.5e9 * 4 and "Infinity Cache" in roof["traffic_source"]
+    roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 128, 524288, 37.6, 25.0, build, 2.0, 25)
     assert roof["traffic"] is None and valu is None and "no profile of TM5120_i8_2dB_25it" in roof["traffic_note"]
 
 

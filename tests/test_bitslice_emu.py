@@ -25,6 +25,7 @@ def emu():
     """decode(code, llrs, maxiters) through the emulated kernel; one shared object per code, the stale ones rebuilt in parallel
     (fully unrolled 64-lane code: ~1 minute each at -O1)."""
     src = [os.path.join(ROOT, "tests", "c", "bitslice_emu.cpp"), os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "decode_ms_bitslice.hpp"),
+           os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "decode_ms_bitslice_split.hpp"), os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "decode_bf_bitslice.hpp"),
            os.path.join(ROOT, "labrador_ldpc_amd", "csrc", "codes.hpp")]
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     libs, jobs = {}, []
@@ -40,15 +41,18 @@ def emu():
         L = ctypes.CDLL(lib)
         L.bs_emu_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         L.bs_emu_decode_bf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        L.bs_emu_decode_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         assert L.bs_emu_code() == oracle.CODES.index(name)
         loaded[oracle.CODES.index(name)] = L
 
-    def decode(code, llrs, maxiters):
+    def decode(code, llrs, maxiters, split=False):
+        """split: the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp), its two halves run alternately"""
         llrs = np.ascontiguousarray(llrs, dtype=np.int8)
         B = llrs.shape[0]
         out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
         it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
-        assert loaded[code].bs_emu_decode(llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
+        fn = loaded[code].bs_emu_decode_split if split else loaded[code].bs_emu_decode
+        assert fn(llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
         return out, it, ok
     def decode_bf(code, hard, maxiters):
         hard = np.ascontiguousarray(hard, dtype=np.uint8)
@@ -62,8 +66,8 @@ def emu():
     return decode
 
 
-def _same(emu, code, llrs, maxiters):
-    o, i, k = emu(code, llrs, maxiters)
+def _same(emu, code, llrs, maxiters, split=False):
+    o, i, k = emu(code, llrs, maxiters, split)
     oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs, maxiters)
     bad = np.nonzero((o != oc).any(axis=1) | (i != ic) | (k != kc))[0]
     assert bad.size == 0, f"frames {bad.tolist()[:8]} differ (iters {i[bad][:8].tolist()} vs {ic[bad][:8].tolist()})"
@@ -80,6 +84,27 @@ def test_emulated_kernel_equals_the_oracle_on_awgn_frames(emu, name):
         for maxiters in (0, 3, 25):
             it, ok = _same(emu, code, llrs, maxiters)
     assert ok.all() and len(set(it.tolist())) > 1        # (the last set at 25: everything converges, after different numbers of iterations)
+
+
+@pytest.mark.parametrize("name", ["TM1280", "TM5120"])
+def test_emulated_two_wave_kernel_equals_the_oracle(emu, name):
+    """The rate-4/5 codes' default kernel: a codeword group shared by two waves, each owning a set of block columns with all their
+    edges (decode_ms_bitslice_split.hpp).  The two halves run stage by stage on one LDS store -- the order the workgroup barriers
+    enforce on the GPU; the runner fails if they ever disagree on a verdict.  Pins: the column partition, the exchange of the partial
+    row states and their merge (two smallest keys of a union, the arg-min slot, sign and parity), the unshared row's parity crossing
+    over, corner inputs with ties everywhere."""
+    code = oracle.CODES.index(name)
+    rng = np.random.default_rng(300 + code)
+    for ebn0, scale, lim, frames in ((3.5, 8.0, 31, 2 * emu.group(code) + 1), (1.0, 30.0, 127, 3), (4.5, 16.0, 127, 5), (4.0, 8.0, 31, emu.group(code) + 2)):
+        llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, np.int8, scale=scale, lim=lim)
+        for maxiters in (0, 3, 25):
+            it, ok = _same(emu, code, llrs, maxiters, split=True)
+    assert ok.all() and len(set(it.tolist())) > 1
+    N = oracle.CODE_N[code] if hasattr(oracle, "CODE_N") else llrs.shape[1]
+    corner = np.stack([np.zeros(N, np.int8), np.full(N, -128, np.int8), np.full(N, 127, np.int8), rng.integers(-128, 128, N).astype(np.int8),
+                       rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)])
+    for maxiters in (25, 1, 2):
+        _same(emu, code, corner, maxiters, split=True)
 
 
 @pytest.mark.parametrize("name", ["TM1280", "TM2048", "TM6144"])

@@ -16,28 +16,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BS = 64                                                       # `variant` of the bit-sliced kernel
 CODES = [LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048, LDPCCode.TM5120, LDPCCode.TM6144, LDPCCode.TM8192]
+# the rate-4/5 codes have two bit-sliced kernels: `variant` 64 (and the default) = two waves per codeword group
+# (csrc/decode_ms_bitslice_split.hpp), `variant` 128 = one wave per group with its LLR planes in a global workspace
+KERNELS = [(c, BS) for c in CODES] + [(LDPCCode.TM1280, 128), (LDPCCode.TM5120, 128)]
+KERNEL_IDS = [f"{c.name}-{v}" for c, v in KERNELS]
 
 
-def _same(code, llrs, maxiters):
-    o, i, k = code.decode_ms_batch(llrs, maxiters, variant=BS)
+def _same(code, llrs, maxiters, variant=BS):
+    o, i, k = code.decode_ms_batch(llrs, maxiters, variant=variant)
     oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs, maxiters)
     bad = np.nonzero((o != oc).any(axis=1) | (i != ic) | (k != kc))[0]
     assert bad.size == 0, f"frames {bad.tolist()[:8]} differ (iters {i[bad][:8].tolist()} vs {ic[bad][:8].tolist()})"
     return i, k
 
 
-@pytest.mark.parametrize("code", CODES)
-def test_bitsliced_kernel_equals_the_oracle(code):
+@pytest.mark.parametrize("code,variant", KERNELS, ids=KERNEL_IDS)
+def test_bitsliced_kernel_equals_the_oracle(code, variant):
     rng = np.random.default_rng(500 + int(code))
     hi = 1.5 if code.k() * 5 == code.n() * 4 else 0.0                 # the rate-4/5 codes converge 1.5 dB later
     for ebn0, scale, lim, frames in ((2.0 + hi, 8.0, 31, 257), (1.0, 30.0, 127, 33), (4.5 + hi, 16.0, 127, 64), (2.5 + hi, 8.0, 31, 1)):
         llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, np.int8, scale=scale, lim=lim)
         for maxiters in (25, 3, 0, 60):
-            _same(code, llrs, maxiters)
+            _same(code, llrs, maxiters, variant)
 
 
-@pytest.mark.parametrize("code", CODES)
-def test_bitsliced_kernel_on_corner_inputs(code):
+@pytest.mark.parametrize("code,variant", KERNELS, ids=KERNEL_IDS)
+def test_bitsliced_kernel_on_corner_inputs(code, variant):
     N = code.n()
     rng = np.random.default_rng(11)
     frames = [np.zeros(N, np.int8), np.full(N, -128, np.int8), np.full(N, 127, np.int8), rng.integers(-128, 128, N).astype(np.int8),
@@ -47,14 +51,14 @@ def test_bitsliced_kernel_on_corner_inputs(code):
     spiked[:, ::7] = -128
     llrs = np.stack(frames + list(spiked) + list(base))
     for maxiters in (25, 1, 2):
-        _same(code, llrs, maxiters)
+        _same(code, llrs, maxiters, variant)
 
 
 def test_bitsliced_kernel_reproduces_the_i8_golden_files():
-    for code in CODES:
+    for code, variant in KERNELS:
         z = np.load(os.path.join(ROOT, "tests", "golden", f"awgn_{code.name}_i8.npz"))
         for maxiters in (25, 4, 0):
-            o, i, k = code.decode_ms_batch(z["llrs"], maxiters, variant=BS)
+            o, i, k = code.decode_ms_batch(z["llrs"], maxiters, variant=variant)
             assert (o == z[f"output_{maxiters}"]).all() and (i == z[f"iters_{maxiters}"]).all() and (k == z[f"success_{maxiters}"]).all()
 
 
@@ -75,9 +79,43 @@ def test_bitsliced_kernel_equals_the_default_i8_kernel_on_a_large_batch(code):
     c = code.decode_ms_batch(llrs, 25)                          # the default: bit-sliced from 1024 ... 32768 groups up, by code
     torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(a, c))
+    if (code, 128) in KERNELS:
+        e = code.decode_ms_batch(llrs, 25, variant=128)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(a, e))
     assert 0.5 < float(a[2].float().mean()) <= 1.0
     small = llrs[:777]                                          # below the threshold the default is the f32-pipe kernel: same results
     assert all(torch.equal(x, y[:777]) for x, y in zip(code.decode_ms_batch(small, 25), a))
+
+
+def test_default_form_can_be_captured_into_a_graph():
+    """No kernel of the default dispatch allocates anything (round 4's first rate-4/5 kernel drew a stream-ordered workspace and had to
+    stay out of graph captures): a captured and replayed decode of a rate-4/5 batch above the bit-sliced threshold equals the oracle."""
+    dev = torch.device("cuda", 0)
+    code = LDPCCode.TM5120
+    rng = np.random.default_rng(8)
+    base, _ = oracle.awgn_llrs(code, rng, 40, 4.0, np.int8, scale=8.0, lim=31)
+    ref = oracle.decode_ms_batch(code, base, 25)
+    frames = 10243                                              # above the default's threshold (2048 groups of four), ragged last group
+    idx = rng.integers(0, len(base), frames)
+    llrs = torch.from_numpy(base[idx]).to(dev)
+    out = torch.empty((frames, code.output_len()), dtype=torch.uint8, device=dev)
+    it = torch.empty((frames,), dtype=torch.int32, device=dev)
+    ok = torch.empty((frames,), dtype=torch.uint8, device=dev)
+
+    def check():
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == ref[0][idx]).all() and (it.cpu().numpy() == ref[1][idx]).all() and (ok.cpu().numpy() == ref[2][idx]).all()
+
+    code.decode_ms_batch(llrs, 25, output=out, iters=it, success=ok)
+    check()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        code.decode_ms_batch(llrs, 25, output=out, iters=it, success=ok)
+    for _ in range(2):
+        out.zero_(); it.fill_(-1); ok.zero_()
+        g.replay()
+        check()
 
 
 def test_variant_64_is_refused_where_it_does_not_exist():
