@@ -10,10 +10,12 @@
 //
 // What the two waves exchange.  An edge's message u needs its block row's state -- the two smallest |v| of the row, the sign product,
 // the arg-min slot -- over ALL the row's edges, and a row's edges lie in both halves (block rows 1 and 2; row 0's three edges are all
-// wave 1's).  Each wave accumulates the row state over ITS edges; once per iteration and shared row the partial states cross through a
-// 24-plane LDS buffer per wave and each wave merges the other's into its own (the two smallest keys of a union are
-// min(a1, b1) and min(max(a1, b1), min(a2, b2)); signs and parities XOR; the arg-min slot follows the smaller min1, wave 0's on a
-// tie, so both waves end with the same state).  Four workgroup barriers per iteration (two waves: they arrive together).
+// wave 1's).  Each wave accumulates the row state over ITS edges.  Once per iteration wave 0 publishes its partial state of row 1 and
+// wave 1 of row 2 (a 24-plane LDS buffer per wave); after a barrier each wave merges the row the OTHER published into its own partial
+// state of that row (the two smallest keys of a union are min(a1, b1) and min(max(a1, b1), min(a2, b2)); signs and parities XOR; the
+// arg-min slot follows the smaller min1, wave 0's on a tie) and writes the merged row back into the other's buffer; after a second
+// barrier each wave fetches the merged state of the row it published.  Both waves then hold the same state.  One merge per wave and
+// two workgroup barriers per iteration (two waves with balanced work: they arrive together).
 //
 // The stages are separate member functions so that tests/c/bitslice_emu.cpp can run the two halves of a group alternately on the CPU.
 #pragma once
@@ -133,36 +135,42 @@ struct SplitGroup {
     }
     static BS_FN V xaddr(V lane, int base, int plane) { return B::add(B::shl(lane, 2), B::c(base + plane * 256)); }
 
-    // ---- stage 2 (per shared row): this wave's partial state of block row R into its exchange buffer.  With the FIRST shared row
-    // goes the parity of the rows only this wave has (the other needs it for the verdict). ----
-    template <int R>
-    BS_FN void stage_write(B &b)
+    // The two shared block rows: this wave PUBLISHES its partial state of row PUB and later fetches that row's merged state; it MERGES
+    // row MRG -- the one the other wave publishes -- and hands the result back.  One merge per wave, two barriers per iteration.
+    static constexpr int nth_shared(int n) { for (int r = 0; r < NROWS; ++r) if (GEO::shared_row(r) && n-- == 0) return r; return -1; }
+    static_assert(nth_shared(1) >= 0 && nth_shared(2) < 0, "exactly two block rows have edges in both halves");
+    static constexpr int PUB = nth_shared(HALF), MRG = nth_shared(1 - HALF);
+
+    template <int R> BS_FN void put_row(B &b, int base)
     {
-        static_assert(GEO::shared_row(R));
         sfor<0, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            b.lds_write32(xaddr(lane, XO, k), d.W1[R][k]);
-            b.lds_write32(xaddr(lane, XO, 8 + k), d.W2[R][k]);
+            b.lds_write32(xaddr(lane, base, k), d.W1[R][k]);
+            b.lds_write32(xaddr(lane, base, 8 + k), d.W2[R][k]);
         });
-        b.lds_write32(xaddr(lane, XO, 16), d.Sn[R]);
-        b.lds_write32(xaddr(lane, XO, 17), d.Pn[R]);
-        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(xaddr(lane, XO, 18 + k), d.argn[R][k]); });
-        if constexpr (R == first_shared()) {
-            V own = B::c(0);
-            sfor<0, NROWS>([&](auto R2_) {
-                constexpr int r2 = decltype(R2_)::value;
-                if constexpr (GEO::has_row(r2) && !GEO::shared_row(r2)) own = B::or_(own, d.Pn[r2]);
-            });
-            b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), own);
-        }
+        b.lds_write32(xaddr(lane, base, 16), d.Sn[R]);
+        b.lds_write32(xaddr(lane, base, 17), d.Pn[R]);
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(xaddr(lane, base, 18 + k), d.argn[R][k]); });
     }
-    static constexpr int first_shared() { for (int r = 0; r < NROWS; ++r) if (GEO::shared_row(r)) return r; return -1; }
 
-    // ---- stage 3 (per shared row): the other wave's partial state of block row R merged into this wave's ----
-    template <int R>
+    // ---- stage 2: the partial state of row PUB into this wave's buffer, with the parity of the rows only this wave has (the other
+    // needs it for the verdict) ----
+    BS_FN void stage_publish(B &b)
+    {
+        put_row<PUB>(b, XO);
+        V own = B::c(0);
+        sfor<0, NROWS>([&](auto R2_) {
+            constexpr int r2 = decltype(R2_)::value;
+            if constexpr (GEO::has_row(r2) && !GEO::shared_row(r2)) own = B::or_(own, d.Pn[r2]);
+        });
+        b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), own);
+    }
+
+    // ---- stage 3: the other wave's partial state of row MRG (in ITS buffer) merged into this wave's; the result goes back into that
+    // buffer, where its owner fetches it ----
     BS_FN void stage_merge(B &b)
     {
-        static_assert(GEO::shared_row(R));
+        constexpr int R = MRG;
         V o1[8], o2[8], oarg[ARG > 0 ? ARG : 1];
         sfor<0, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
@@ -171,8 +179,8 @@ struct SplitGroup {
         });
         const V os = b.lds_read32(xaddr(lane, XT, 16)), op = b.lds_read32(xaddr(lane, XT, 17));
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; oarg[k] = b.lds_read32(xaddr(lane, XT, 18 + k)); });
-        if constexpr (R == first_shared()) extra_fail = b.lds_read32(xaddr(lane, XT, LAY::XEXTRA));
-        // take the other's min1 where it is smaller -- wave 0's wins a tie, in both waves
+        extra_fail = b.lds_read32(xaddr(lane, XT, LAY::XEXTRA));
+        // take the other's min1 where it is smaller -- wave 0's wins a tie, whichever wave merges
         V take;
         if constexpr (HALF == 0) take = A::less_than(o1, d.W1[R]);                  // other (wave 1) strictly smaller
         else take = B::not_(A::less_than(d.W1[R], o1));                             // mine (wave 1) not strictly smaller
@@ -189,9 +197,24 @@ struct SplitGroup {
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = op3<TT_MUX>(take, oarg[k], d.argn[R][k]); });
         d.Sn[R] = B::xor_(d.Sn[R], os);
         d.Pn[R] = B::xor_(d.Pn[R], op);
+        put_row<R>(b, XT);
     }
 
-    // ---- stage 4: new state -> old state, the verdict of iteration `it` (the same in both waves) ----
+    // ---- stage 4: the merged state of row PUB, which the other wave left in this wave's buffer ----
+    BS_FN void stage_fetch(B &b)
+    {
+        constexpr int R = PUB;
+        sfor<0, 8>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            d.W1[R][k] = b.lds_read32(xaddr(lane, XO, k));
+            d.W2[R][k] = b.lds_read32(xaddr(lane, XO, 8 + k));
+        });
+        d.Sn[R] = b.lds_read32(xaddr(lane, XO, 16));
+        d.Pn[R] = b.lds_read32(xaddr(lane, XO, 17));
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = b.lds_read32(xaddr(lane, XO, 18 + k)); });
+    }
+
+    // ---- stage 5: new state -> old state, the verdict of iteration `it` (the same in both waves) ----
     BS_FN void stage_finish(B &b, uint32_t it)
     {
         const V fail = B::or_(d.finish_iteration(b), extra_fail);
@@ -251,19 +274,14 @@ template <int CODE, class B, int HALF, class SYNC>
 BS_FN void decode_group_split(B &b, SplitGroup<CODE, B, HALF> &g, const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, uint32_t batch,
                               uint32_t maxiters, uint32_t group, SYNC sync)
 {
-    using GEO = Geo<CODE, HALF>;
     g.prologue(b, llrs, out, iters, ok, batch, maxiters, group);
     for (uint32_t it = 0; it < maxiters && g.running(); ++it) {
         g.stage_columns(b);
-        sfor<0, GEO::NROWS>([&](auto R_) {
-            constexpr int r = decltype(R_)::value;
-            if constexpr (GEO::shared_row(r)) {
-                sync();                        // the other wave has read what this buffer held
-                g.template stage_write<r>(b);
-                sync();                        // both partial states are in place
-                g.template stage_merge<r>(b);
-            }
-        });
+        g.stage_publish(b);                    // (own buffer: the other wave last touched it before the previous barrier)
+        sync();                                // both partial states are in place
+        g.stage_merge(b);                      // (the OTHER wave's buffer: read, then overwritten with the merged row)
+        sync();                                // both merged rows are in place
+        g.stage_fetch(b);                      // (own buffer)
         g.stage_finish(b, it);
     }
     sync();                                    // (the epilogue's hard-decision words alias nothing the other wave reads, but the next

@@ -121,13 +121,9 @@ int run_split(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, si
         for (uint32_t it = 0; it < maxiters && w0.running(); ++it) {
             if (w0.running() != w1.running()) return 2;                  // the two waves must agree on every verdict
             w0.stage_columns(b0); w1.stage_columns(b1);
-            sfor<0, GEO::NROWS>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                if constexpr (GEO::shared_row(r)) {
-                    w0.template stage_write<r>(b0); w1.template stage_write<r>(b1);
-                    w0.template stage_merge<r>(b0); w1.template stage_merge<r>(b1);
-                }
-            });
+            w0.stage_publish(b0); w1.stage_publish(b1);
+            w0.stage_merge(b0); w1.stage_merge(b1);
+            w0.stage_fetch(b0); w1.stage_fetch(b1);
             w0.stage_finish(b0, it); w1.stage_finish(b1, it);
             if (w0.frozen_mask != w1.frozen_mask) return 3;
         }
