@@ -112,3 +112,14 @@ def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
         assert sum(1 for t in loop if t.startswith("v_bitop3_b32")) > 0.6 * len(loop) - 200      # ... which is Boolean arithmetic
         seen += 1
     assert seen == 6
+    # the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp): no scratch memory ANYWHERE (its state fits
+    # the registers: nothing is spilled, prologue and epilogue included), no global access inside the iterations (the LLR planes live in
+    # LDS), and exactly two workgroup barriers per iteration and wave
+    seen = 0
+    for name, body in kernels.items():
+        if "decode_ms_bs_split_kernel" not in name:
+            continue
+        assert not any(t.startswith("scratch_") for t in body), name
+        assert sum(1 for t in body if t.startswith("s_barrier")) == 2 * 2 + 2, name           # two halves x two per iteration, + one per half before the epilogue
+        seen += 1
+    assert seen == 2
