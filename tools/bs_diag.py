@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from labrador_ldpc_amd import LDPCCode
 dev = torch.device("cuda", 0)
-for code, frames in ((LDPCCode.TM5120, 262144), (LDPCCode.TM1280, 1048576), (LDPCCode.TM8192, 131072), (LDPCCode.TM2048, 524288), (LDPCCode.TM6144, 131072)):
+CASES = ((LDPCCode.TM5120, 262144), (LDPCCode.TM1280, 1048576), (LDPCCode.TM8192, 131072), (LDPCCode.TM2048, 524288), (LDPCCode.TM6144, 131072))
+if len(sys.argv) > 1:
+    CASES = tuple(c for c in CASES if c[0].name in sys.argv[1:])
+for code, frames in CASES:
     g = torch.Generator(device=dev); g.manual_seed(3)
     llrs = torch.randint(-40, 41, (frames, code.n()), dtype=torch.int8, device=dev, generator=g)      # noise: 25 iterations each
     out = code.decode_ms_batch(llrs, 25, variant=64); torch.cuda.synchronize()
