@@ -34,8 +34,11 @@
 // The code below is written against a small backend `B` (one wave's registers as values of type B::V): HipBackend compiles it
 // for gfx950, tests/bitslice_emu.cpp runs the same text lane by lane on the CPU, where it is compared with the oracle.
 //
-// BS_DIAG (never defined by the library's Makefile; tools/bs_diag_build.sh): timing-only builds that leave out one kind of memory
-// access -- wrong results -- to bound what hiding its latency could give (profiles/r04_kbench/bs_diag.txt).
+//  * SCHEDULE OF AN ITERATION (round 5).  The block columns are taken in an order that lets block row 0 -- three edges -- finish
+//    first (Geo::COL_ORDER); a row's running state starts with its first edge (no all-ones initial state, no compare for that
+//    edge) and REPLACES the row's old state the moment its last edge is done, so that old and new state of a row are live together
+//    only between its first and its last edge.  Hard decisions live in LDS where that frees the registers for one more wave per
+//    SIMD (Geo::HARD_LDS).
 #pragma once
 
 #include <cstdint>
@@ -152,52 +155,94 @@ struct Geo {
     // ordinal of block column c among the owned transmitted ones, and their number
     static constexpr int llr_slot(int c) { int s = 0; for (int i = 0; i < c; ++i) s += (owns_col(i) && i < NTX) ? 1 : 0; return s; }
     static constexpr int NTX_OWN = llr_slot(NCOLS);
+    // ordinal of block column c among the owned ones (hard-decision words)
+    static constexpr int col_slot(int c) { int s = 0; for (int i = 0; i < c; ++i) s += owns_col(i) ? 1 : 0; return s; }
+    static constexpr int NCOLS_OWN = col_slot(NCOLS);
+
+    // ---- the order in which an iteration takes the owned block columns.  The columns that hold block row 0's edges come first (the
+    // one with the fewest edges first): row 0 has three edges in two columns, so its running state is complete -- and becomes its old
+    // state -- early in the iteration, and the other rows' running states start after it (they start with their first edge).
+    struct ColOrder { int col[16]; int n; };
+    static constexpr bool col_has_row(int c, int r) { for (int b = 0; b < NB; ++b) if (P.blk[b].col == c && P.blk[b].row == r) return true; return false; }
+    static constexpr ColOrder col_order()
+    {
+        ColOrder o{};
+        bool used[16] = {};
+        for (int pass = 0; pass < 2; ++pass)                                     // pass 0: columns with an edge in block row 0
+            for (;;) {
+                int best = -1;
+                for (int c = 0; c < NCOLS; ++c) {
+                    if (used[c] || !owns_col(c) || (pass == 0 && !col_has_row(c, 0))) continue;
+                    if (best < 0 || (pass == 0 && col_degree(c) < col_degree(best))) best = c;
+                }
+                if (best < 0) break;
+                used[best] = true;
+                o.col[o.n++] = best;
+            }
+        return o;
+    }
+    static constexpr ColOrder COL_ORDER = col_order();
+    static constexpr int col_pos(int c) { for (int i = 0; i < COL_ORDER.n; ++i) if (COL_ORDER.col[i] == c) return i; return -1; }
+    // position of owned edge e in the order its CHECK side is processed: column position, then block order inside the column
+    static constexpr int proc_pos(int e) { return col_pos(P.blk[e].col) * MAX_BLOCKS + e; }
+    // first / last owned edge of block row r in that order
+    static constexpr int first_edge(int r)
+    {
+        int best = -1;
+        for (int e = 0; e < NB; ++e) if (owns(e) && P.blk[e].row == r && (best < 0 || proc_pos(e) < proc_pos(best))) best = e;
+        return best;
+    }
+    static constexpr int last_edge(int r)
+    {
+        int best = -1;
+        for (int e = 0; e < NB; ++e) if (owns(e) && P.blk[e].row == r && (best < 0 || proc_pos(e) > proc_pos(best))) best = e;
+        return best;
+    }
     // the order in which an iteration uses the permutation-table entries (entry 2x = check -> variable alignment of exchanged edge x,
-    // 2x + 1 = the way back): block column by block column, the variable side's edges, then the check side's
+    // 2x + 1 = the way back): block column by block column in COL_ORDER, the variable side's edges, then the check side's
     struct PermOrder { int idx[2 * NB + 1]; int pos[2 * NB + 1]; };
     static constexpr PermOrder perm_order()
     {
         PermOrder o{};
         int n = 0;
-        for (int c = 0; c < NCOLS; ++c)
+        for (int i = 0; i < COL_ORDER.n; ++i)
             for (int side = 0; side < 2; ++side)
                 for (int e = 0; e < NB; ++e)
-                    if (P.blk[e].col == c && owns(e) && !local(e)) o.idx[n++] = exch_of(e) * 2 + side;
+                    if (P.blk[e].col == COL_ORDER.col[i] && owns(e) && !local(e)) o.idx[n++] = exch_of(e) * 2 + side;
         for (int i = 0; i < n; ++i) o.pos[o.idx[i]] = i;
         return o;
     }
     static constexpr PermOrder PERM_ORDER = perm_order();
     static constexpr int perm_after(int idx) { return PERM_ORDER.idx[(PERM_ORDER.pos[idx] + 1) % (2 * NX)]; }
-    // The rate-4/5 codes keep their LLR planes in a global workspace (one slot per resident wave, re-read from L2 / MALL in every
-    // iteration, 20 KB per wave): in LDS they alone would take the 160 KB of a CU at two waves per SIMD.
-    static constexpr bool LLR_GLOBAL = !SPLIT && P.n_blocks > 30;
     static constexpr int LLR_WORDS = NTX_OWN * 8 * 64;             // words of LLR planes per wave
-    // Register diet of the rate-4/5 codes (39 edges: 218 planes of state before any temporary, against 256 registers at two waves
-    // per SIMD): the hard decisions and the whole state of block row 0 -- three edges per iteration -- live in LDS, the lane
-    // permutations are 16-bit entries.
-    static constexpr bool HARD_LDS = LLR_GLOBAL, ROW0_LDS = LLR_GLOBAL, PERM16 = P.n_blocks > 30;
-    // ... and every state update and every use of the old row state is pinned to its place in the program (Decoder::pin): without
-    // that the instruction selector's data-flow order keeps ~500 values live on these codes.  The smaller codes fit their
-    // registers without the pins and run 6 % faster with the freedom (TM8192 16.9 against 15.9 M codewords/s).
-#ifndef BS_SPLIT_PINNED
-#define BS_SPLIT_PINNED 0          // (measured: 0 -> 36.8, 1 -> 36.3, 2 -> 34.4 M codewords/s on TM5120 at 4 dB, profiles/r04_kbench/split_rate.txt)
+    // the rate-4/5 codes (39 edges: 218 planes of state before any temporary) exist only in the two-waves-per-group form
+    static constexpr bool TWO_WAVES = P.n_blocks > 30;
+    // Every state update of the rate-2/3 codes is pinned to its place in the program (Decoder::pin_update): without that the
+    // instruction selector's data-flow order keeps values whose next use is an iteration away live to the end of the block.  The
+    // rate-1/2 codes fit their registers without the pins and run 6 % faster with the freedom (TM8192 16.9 against 15.9 M codewords/s);
+    // the two-wave form of the rate-4/5 codes measured 36.8 (no pins) against 36.3 / 34.4 (profiles/r04_kbench/split_rate.txt).
+    static constexpr int PINNED = (!SPLIT && P.n_blocks > 20) ? 1 : 0;
+    // Hard decisions in LDS instead of one register per block column (one ds_write per column and iteration; a read as well where a
+    // wave holds several codewords, whose finished ones keep their decisions): the rate-1/2 codes, which that brings under the 168
+    // registers of three waves per SIMD.
+#ifndef BS_HARD_LDS
+#define BS_HARD_LDS 1
 #endif
-    static constexpr int PINNED = LLR_GLOBAL ? 2 : SPLIT ? BS_SPLIT_PINNED : (P.n_blocks > 20 ? 1 : 0);       // 2: everything; 1: the state updates only (rate 2/3)
-    static constexpr int ROW_OLD = 15 + ARG, ROW_NEW = 18 + ARG;               // planes of a row's old / running state
-    // LDS: lane permutations of the exchanged blocks [NX][2 directions][64] (source lane address | rotate amount << 8; constant for
-    // the kernel's lifetime), hard-decision words [NCOLS][64], row 0's state [ROW_OLD + ROW_NEW][64] (if ROW0_LDS), LLR planes
-    // [NTX][8][64] (unless in the global workspace), a 2048-byte staging slab for the LLR transposition (aliases row 0's state,
-    // which is initialised after the LLRs are in place)
+    static constexpr bool HARD_LDS = !SPLIT && P.n_blocks <= 20 && BS_HARD_LDS;
+    static constexpr int ROW_NEW = 18 + ARG;                                   // planes of a row's running state
+    // LDS of a wave: lane permutations of the exchanged blocks [NX][2 directions][64] as 16-bit entries (source lane address | rotate
+    // amount << 8; constant for the kernel's lifetime), hard-decision words [NCOLS][64] -- which double as the 2048-byte staging slab
+    // of the LLR transposition (prologue only) --, LLR planes [NTX][8][64].
     // Split mode: a wave's private area is [permutations | LLR planes]; the hard-decision words of the epilogue alias the LLR planes
     // (dead by then) and the staging slab is the wave's exchange buffer, which lies behind both private areas (SplitLayout).
-    static constexpr int LDS_PERM = 0, LDS_PERM_END = LDS_PERM + NX * 2 * 64 * (PERM16 ? 2 : 4);
-    static constexpr int LDS_HARD = SPLIT ? LDS_PERM_END : LDS_PERM_END, LDS_ROW0 = SPLIT ? LDS_PERM_END : LDS_HARD + NCOLS * 256,
-                         LDS_LLR = LDS_ROW0 + (ROW0_LDS ? (ROW_OLD + ROW_NEW) * 256 : 0),
-                         LDS_PRIVATE = LDS_LLR + (LLR_GLOBAL ? 0 : LLR_WORDS * 4),
-                         LDS_STAGE = ROW0_LDS ? LDS_ROW0 : LDS_PRIVATE,        // (split mode: Decoder::stage_base overrides it)
-                         LDS_BYTES = ROW0_LDS ? LDS_PRIVATE : LDS_STAGE + 2048;
-    static_assert(!ROW0_LDS || (ROW_OLD + ROW_NEW) * 256 >= 2048);
-    static_assert(!SPLIT || NCOLS * 256 <= LLR_WORDS * 4, "the epilogue's hard-decision words alias the LLR planes");
+    static constexpr int LDS_PERM = 0, LDS_PERM_END = LDS_PERM + NX * 2 * 64 * 2;
+    static constexpr int HARD_BYTES = NCOLS_OWN * 256 > 2048 ? NCOLS_OWN * 256 : 2048;
+    static constexpr int LDS_HARD = LDS_PERM_END, LDS_STAGE = LDS_HARD,
+                         LDS_LLR = SPLIT ? LDS_PERM_END : LDS_HARD + HARD_BYTES,
+                         LDS_PRIVATE = LDS_LLR + LLR_WORDS * 4,
+                         LDS_BYTES = LDS_PRIVATE;
+    static_assert(!SPLIT || NCOLS_OWN * 256 <= LLR_WORDS * 4, "the epilogue's hard-decision words alias the LLR planes");
+    static_assert(NCOLS <= 16);
 };
 
 // ---- arithmetic on bit planes -------------------------------------------------------------------------------------------
@@ -256,12 +301,13 @@ struct Decoder {
 
     // lane constants
     V lane, q, ll, cwbase;
-    // old row state (read-only during an iteration) and per-edge bits
+    // old row state (read-only between a row's first and last edge of an iteration) and per-edge bits
     V m1[NROWS][7], m2[NROWS][7], S[NROWS], arg[NROWS][ARG];
     V sv[NB], nz[NB];
-    // new row state of the running iteration: keys (8 planes), sign product, parity, arg-min slot
+    // running state of the rows whose edges are being processed: keys (8 planes), sign product, parity, arg-min slot
     V W1[NROWS][8], W2[NROWS][8], Sn[NROWS], Pn[NROWS], argn[NROWS][ARG];
-    V hard[NCOLS];
+    V hard[NCOLS];                      // (unused with Geo::HARD_LDS)
+    V fail;                             // OR of the parities of the rows finished in this iteration (decoder.rs:453)
 
     BS_FN void init_lane(B &b)
     {
@@ -270,6 +316,16 @@ struct Decoder {
         q = B::and_(B::shr(lane, ilog2c(L)), B::c(3));
         cwbase = B::and_(lane, B::c(~(W - 1) & 63));
     }
+
+    BS_FN void reinit_lane()
+    {
+        B::pin(lane);
+        ll = B::and_(lane, B::c(L - 1));
+        q = B::and_(B::shr(lane, ilog2c(L)), B::c(3));
+        cwbase = B::and_(lane, B::c(~(W - 1) & 63));
+    }
+
+    BS_FN V hard_addr(int c) const { return B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + GEO::col_slot(c) * 256)); }
 
     BS_FN void reset_state(B &b)
     {
@@ -280,14 +336,13 @@ struct Decoder {
                 sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
                 S[r] = B::c(0);
                 sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
-                spill_old<r>(b);
             }
         });
         sfor<0, NB>([&](auto E_) { constexpr int e = decltype(E_)::value; if constexpr (GEO::owns(e)) { sv[e] = B::c(0); nz[e] = B::c(0); } });
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) {
-                if constexpr (GEO::HARD_LDS) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), B::c(0));
+                if constexpr (GEO::HARD_LDS) b.lds_write32(hard_addr(c), B::c(0));        // (max_iters = 0: all-zero output, decoder.rs:466-473)
                 else hard[c] = B::c(0);
             }
         });
@@ -329,10 +384,6 @@ struct Decoder {
     BS_FN void edge_u(V &su, V (&mg)[7])
     {
         constexpr int r = GEO::P.blk[E].row, slot = GEO::slot_of(E);
-        // (everything below depends on the OLD row state only, which exists from the top of the iteration: without the pins the
-        // instruction selector computes every edge's u there and keeps it)
-        sfor<0, ARG>([&](auto K_) { pin(arg[r][decltype(K_)::value]); });
-        pin(S[r]);
         const V sel = is_arg<r, slot>();
         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = op3<TT_MUX>(sel, m2[r][k], m1[r][k]); });
         su = B::xor_(S[r], sv[E]);
@@ -372,20 +423,12 @@ struct Decoder {
         amt = B::add(phi, over);                                                  // rotr by phi + wrap
     }
 
-    static BS_FN void pin(V &x) { if constexpr (GEO::PINNED >= 2) B::pin(x); }
     static BS_FN void pin_update(V &x) { if constexpr (GEO::PINNED >= 1) B::pin(x); }
 
-    template <int IDX> BS_FN V perm_entry(B &b) const
-    {
-#if defined(BS_DIAG) && (BS_DIAG & 2)
-        return B::add(B::shl(lane, 2), B::c((IDX * 37) & 0x1F00));   // DIAGNOSTIC: no table read (wrong results)
-#endif
-        if constexpr (GEO::PERM16) return b.lds_read_u16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)));
-        else return b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + IDX * 256)));
-    }
+    template <int IDX> BS_FN V perm_entry(B &b) const { return b.lds_read_u16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128))); }
     // The entries are used in a fixed order (Geo::PERM_ORDER), so each use hands out the entry read during the PREVIOUS use and starts
     // the read of the next one: an LDS round trip in front of every edge's eight ds_bpermute, with one other wave on the SIMD to hide
-    // it behind, cost 10-12 % (profiles/r04_kbench/bs_diag.txt, BS_DIAG=2).  One register.
+    // it behind, cost 10-12 % (profiles/r04_kbench/bs_diag.txt).  One register.
     V pnext;
     BS_FN void prime_perm(B &b) { pnext = perm_entry<GEO::PERM_ORDER.idx[0]>(b); }
     template <int IDX> BS_FN V take_perm(B &b)
@@ -394,53 +437,10 @@ struct Decoder {
         pnext = perm_entry<GEO::perm_after(IDX)>(b);
         return a;
     }
-    template <int IDX> BS_FN void put_perm_entry(B &b, V w) const
-    {
-        if constexpr (GEO::PERM16) b.lds_write16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)), w);
-        else b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_PERM + IDX * 256)), w);
-    }
-
-    // ---- a row whose state lives in LDS (row 0 of the rate-4/5 codes): the member arrays are temporaries, filled before a use
-    // and spilled after a change, so they hold registers only around the row's three edges ----
-    template <int R> static constexpr bool in_lds() { return GEO::ROW0_LDS && R == 0; }
-    BS_FN V row_addr(int plane) const { return B::add(B::shl(lane, 2), B::c(GEO::LDS_ROW0 + plane * 256)); }
-    template <int R> BS_FN void fill_old(B &b)
-    {
-        if constexpr (in_lds<R>()) {
-            sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[R][k] = b.lds_read32(row_addr(k)); m2[R][k] = b.lds_read32(row_addr(7 + k)); });
-            S[R] = b.lds_read32(row_addr(14));
-            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[R][k] = b.lds_read32(row_addr(15 + k)); });
-        }
-    }
-    template <int R> BS_FN void spill_old(B &b)
-    {
-        if constexpr (in_lds<R>()) {
-            sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(k), m1[R][k]); b.lds_write32(row_addr(7 + k), m2[R][k]); });
-            b.lds_write32(row_addr(14), S[R]);
-            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(15 + k), arg[R][k]); });
-        }
-    }
-    template <int R> BS_FN void fill_new(B &b)
-    {
-        if constexpr (in_lds<R>()) {
-            constexpr int o = GEO::ROW_OLD;
-            sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[R][k] = b.lds_read32(row_addr(o + k)); W2[R][k] = b.lds_read32(row_addr(o + 8 + k)); });
-            Sn[R] = b.lds_read32(row_addr(o + 16)); Pn[R] = b.lds_read32(row_addr(o + 17));
-            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; argn[R][k] = b.lds_read32(row_addr(o + 18 + k)); });
-        }
-    }
-    template <int R> BS_FN void spill_new(B &b)
-    {
-        if constexpr (in_lds<R>()) {
-            constexpr int o = GEO::ROW_OLD;
-            sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(o + k), W1[R][k]); b.lds_write32(row_addr(o + 8 + k), W2[R][k]); });
-            b.lds_write32(row_addr(o + 16), Sn[R]); b.lds_write32(row_addr(o + 17), Pn[R]);
-            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(row_addr(o + 18 + k), argn[R][k]); });
-        }
-    }
+    template <int IDX> BS_FN void put_perm_entry(B &b, V w) const { b.lds_write16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)), w); }
 
     // The permutations depend on the lane only: computed once per kernel into LDS.  ds_bpermute_b32 reads bits 7:2 of its address
-    // and v_alignbit_b32 bits 4:0 of its shift, so one word carries both: address | amount << 8.
+    // and v_alignbit_b32 bits 4:0 of its shift, so one 16-bit entry carries both: address | amount << 8.
     BS_FN void init_perm_tables(B &b) const
     {
         sfor<0, NB>([&](auto E_) {
@@ -455,48 +455,46 @@ struct Decoder {
         });
     }
 
+    // ---- a row's running state becomes its old state; minima back to magnitudes: (key + 1) >> 1 = (key >> 1) + (key & 1) ----
+    template <int R> BS_FN void finish_row()
+    {
+        auto to_mag = [&](const V (&key)[8], V (&mag)[7]) {
+            V c = key[0];
+            sfor<0, 7>([&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                mag[k] = B::xor_(key[k + 1], c);
+                c = B::and_(key[k + 1], c);
+            });
+        };
+        to_mag(W1[R], m1[R]);
+        to_mag(W2[R], m2[R]);
+        S[R] = Sn[R];
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[R][k] = argn[R][k]; });
+        fail = B::or_(fail, Pn[R]);                                                   // non-zero bits = unsatisfied checks (:453)
+    }
+
     // ---- one iteration (decoder.rs:380-450), block column by block column -------------------------------------------
     // `frozen`: all ones in the lanes of codewords that are finished (their hard decisions stay as they are)
-    BS_FN V iteration(B &b, V frozen, const uint32_t *ws)
+    BS_FN V iteration(B &b, V frozen)
     {
-        begin_iteration(b);
-        columns(b, frozen, ws);
+        columns(b, frozen);
         return finish_iteration(b);
     }
-    // the running state of every block row this wave has edges in: two keys of +127, no sign, no parity
-    BS_FN void begin_iteration(B &b)
+    // the owned block columns in Geo::COL_ORDER: variable side, then check side, of each.  A row that only this wave has edges in is
+    // finished with its last edge; a row shared with another wave (split mode) stays a partial running state for the exchange.
+    BS_FN void columns(B &b, V frozen)
     {
-        sfor<0, NROWS>([&](auto R_) {
-            constexpr int r = decltype(R_)::value;
-            if constexpr (GEO::has_row(r)) {
-                W1[r][0] = B::c(0); W2[r][0] = B::c(0);                              // key of +127 = 254 (decoder.rs:414-415: maxval)
-                sfor<1, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = B::c(0xFFFFFFFFu); W2[r][k] = B::c(0xFFFFFFFFu); });
-                Sn[r] = B::c(0); Pn[r] = B::c(0);
-                sfor<0, ARG>([&](auto K_) { argn[r][decltype(K_)::value] = B::c(0); });
-                spill_new<r>(b);
-            }
-        });
-    }
-    // the owned block columns: variable side, then check side, of each
-    BS_FN void columns(B &b, V frozen, const uint32_t *ws)
-    {
-        sfor<0, NCOLS>([&](auto C_) {
-            constexpr int c = decltype(C_)::value;
-            if constexpr (GEO::owns_col(c)) {
+        fail = B::c(0);
+        sfor<0, GEO::COL_ORDER.n>([&](auto I_) {
+            constexpr int c = GEO::COL_ORDER.col[decltype(I_)::value];
             B::fence();            // keep the compiler from hoisting the next column's loads over this one's arithmetic (register pressure)
             // ---- variable side: marginal of block column c (decoder.rs:382-383, :408) ----
             V va[8];
             if constexpr (c < NTX) {
-                V at = B::shl(lane, 2);
-                pin(at);                              // (the loads of this column start here, not at the top of the iteration)
+                const V at = B::shl(lane, 2);
                 sfor<0, 8>([&](auto K_) {
                     constexpr int k = decltype(K_)::value;
-#if defined(BS_DIAG) && (BS_DIAG & 1)
-                    if constexpr (GEO::LLR_GLOBAL) va[k] = B::xor_(at, B::c(0x9E3779B9u * (c * 8 + k + 1)));      // DIAGNOSTIC: no load (wrong results)
-#else
-                    if constexpr (GEO::LLR_GLOBAL) va[k] = b.gload32(ws, B::add(at, B::c((c * 8 + k) * 256)), B::c(0xFFFFFFFFu));
-#endif
-                    else va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)));
+                    va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)));
                 });
             } else {
                 sfor<0, 8>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
@@ -505,28 +503,23 @@ struct Decoder {
                 constexpr int e = decltype(E_)::value;
                 if constexpr (GEO::P.blk[e].col == c) {
                     V su, mg[7];
-                    fill_old<GEO::P.blk[e].row>(b);
                     edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
                         const V addr = take_perm<GEO::exch_of(e) * 2 + 0>(b);
                         const V amt = B::shr(addr, 8);
-#if defined(BS_DIAG) && (BS_DIAG & 4)
-                        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(B::xor_(addr, mg[k]), amt); });   // DIAGNOSTIC
-                        su = B::rotr(B::xor_(addr, su), amt);
-#else
                         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
                         su = B::rotr(b.bperm(addr, su), amt);
-#endif
                     }
                     A::template sat_addsub<false>(va, su, mg);
-                    sfor<0, 8>([&](auto K_) { pin(va[decltype(K_)::value]); });
                     B::fence();
                 }
             });
-            if constexpr (GEO::HARD_LDS) {               // read-modify-write, branch-free (an EXEC-masked store splits the loop body into
-                const V at = B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256));      // blocks and wrecks the register allocation)
-                b.lds_write32(at, op3<TT_MUX>(frozen, b.lds_read32(at), va[7]));
-            } else hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
+            // hard decisions (decoder.rs:457-461): a wave that holds ONE codeword stops with it, so nothing is ever frozen there
+            if constexpr (GEO::HARD_LDS) {
+                if constexpr (G == 1) b.lds_write32(hard_addr(c), va[7]);
+                else b.lds_write32(hard_addr(c), op3<TT_MUX>(frozen, b.lds_read32(hard_addr(c)), va[7]));     // (branch-free: an EXEC-masked
+            } else if constexpr (G == 1) hard[c] = va[7];                                                      //  store would split the loop body)
+            else hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
             // ---- check side of the same edges (decoder.rs:419-447) ----
             sfor<0, NB>([&](auto E_) {
                 constexpr int e = decltype(E_)::value;
@@ -536,17 +529,12 @@ struct Decoder {
                     if constexpr (!GEO::local(e)) {
                         const V addr = take_perm<GEO::exch_of(e) * 2 + 1>(b);
                         const V amt = B::shr(addr, 8);
-#if defined(BS_DIAG) && (BS_DIAG & 4)
-                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(B::xor_(addr, va[k]), amt); });   // DIAGNOSTIC
-#else
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
-#endif
                     } else {
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
                     }
                     const V pbit = nv[7];                                            // hard bit of the marginal (:445-447)
                     V su, mg[7];
-                    fill_old<r>(b);                                                  // (an LDS row: its old state is dead again after edge_u)
                     edge_u<e>(su, mg);
                     A::template sat_addsub<true>(nv, su, mg);                        // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
@@ -560,63 +548,120 @@ struct Decoder {
                     key[0] = op3<TT_KEY0>(vs, all1, key[7]);
                     sv[e] = vs;
                     nz[e] = op3<TT_OR3>(op3<TT_OR3>(key[1], key[2], key[3]), op3<TT_OR3>(key[4], key[5], key[6]), B::or_(key[7], vs));
-                    fill_new<r>(b);                                                  // (an LDS row: filled only now, when nv's temporaries are dead)
-                    Pn[r] = B::xor_(Pn[r], pbit);                                    // parity of the marginals' hard bits
-                    Sn[r] = B::xor_(Sn[r], vs);                                      // product of the signs (:438-441)
-                    // two running minima (:430-434)
-                    const V lt1 = A::less_than(key, W1[r]);
-                    const V lt2 = A::less_than(key, W2[r]);
-                    sfor<0, 8>([&](auto K_) {
-                        constexpr int k = decltype(K_)::value;
-                        const V t = op3<TT_MUX>(lt2, key[k], W2[r][k]);
-                        W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], t);
-                        W1[r][k] = op3<TT_MUX>(lt1, key[k], W1[r][k]);
-                    });
-                    sfor<0, ARG>([&](auto K_) {
-                        constexpr int k = decltype(K_)::value;
-                        argn[r][k] = ((slot >> k) & 1) ? B::or_(argn[r][k], lt1) : B::andn(argn[r][k], lt1);
-                    });
+                    if constexpr (e == GEO::first_edge(r)) {
+                        // the row's running state STARTS with this edge: every key is <= 254 = the key of maxval (decoder.rs:414-415), so
+                        // after one insertion min1 = this key and min2 = 254 whatever the key -- no compare; the arg-min slot is this
+                        // edge's (if the key IS 254 the reference's strict `<` would leave the slot alone, but then min1 = min2 and the
+                        // slot selects between equal values)
+                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = key[k]; W2[r][k] = B::c(k == 0 ? 0u : 0xFFFFFFFFu); });
+                        Pn[r] = pbit;
+                        Sn[r] = vs;
+                        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; argn[r][k] = B::c(((slot >> k) & 1) ? 0xFFFFFFFFu : 0u); });
+                    } else {
+                        Pn[r] = B::xor_(Pn[r], pbit);                                // parity of the marginals' hard bits
+                        Sn[r] = B::xor_(Sn[r], vs);                                  // product of the signs (:438-441)
+                        // two running minima (:430-434)
+                        const V lt1 = A::less_than(key, W1[r]);
+                        const V lt2 = A::less_than(key, W2[r]);
+                        sfor<0, 8>([&](auto K_) {
+                            constexpr int k = decltype(K_)::value;
+                            const V t = op3<TT_MUX>(lt2, key[k], W2[r][k]);
+                            W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], t);
+                            W1[r][k] = op3<TT_MUX>(lt1, key[k], W1[r][k]);
+                        });
+                        sfor<0, ARG>([&](auto K_) {
+                            constexpr int k = decltype(K_)::value;
+                            argn[r][k] = ((slot >> k) & 1) ? B::or_(argn[r][k], lt1) : B::andn(argn[r][k], lt1);
+                        });
+                    }
                     // The instruction selector orders a basic block by its data flow alone and would compute values whose next use is
                     // an iteration away (the new v's zero-ness, the row minima) at the END of the block, holding their operands -- seven
-                    // key planes per edge -- in registers until then: 500 live values on the rate-4/5 codes.  An opaque use pins each
-                    // update where it is written.
+                    // key planes per edge -- in registers until then.  An opaque use pins each update where it is written (rate 2/3).
                     pin_update(sv[e]); pin_update(nz[e]); pin_update(Sn[r]); pin_update(Pn[r]);
                     sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_update(W1[r][k]); pin_update(W2[r][k]); });
                     sfor<0, ARG>([&](auto K_) { pin_update(argn[r][decltype(K_)::value]); });
-                    spill_new<r>(b);
+                    if constexpr (e == GEO::last_edge(r) && !GEO::shared_row(r)) finish_row<r>();
                     B::fence();
                 }
             });
-            }
         });
     }
-    // ---- the new row state becomes the old one; minima back to magnitudes: (key + 1) >> 1 = (key >> 1) + (key & 1) ----
-    BS_FN V finish_iteration(B &b)
+    // ---- split mode: the rows shared with the other wave are finished after their exchange; returns the unsatisfied checks ----
+    BS_FN V finish_iteration(B &)
     {
-        V fail = B::c(0);
         sfor<0, NROWS>([&](auto R_) {
             constexpr int r = decltype(R_)::value;
-            if constexpr (GEO::has_row(r)) {
-            auto to_mag = [&](const V (&key)[8], V (&mag)[7]) {
-                V c = key[0];
-                sfor<0, 7>([&](auto K_) {
-                    constexpr int k = decltype(K_)::value;
-                    mag[k] = B::xor_(key[k + 1], c);
-                    c = B::and_(key[k + 1], c);
-                });
-            };
-            fill_new<r>(b);
-            to_mag(W1[r], m1[r]);
-            to_mag(W2[r], m2[r]);
-            S[r] = Sn[r];
-            sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[r][k] = argn[r][k]; });
-            fail = B::or_(fail, Pn[r]);
-            spill_old<r>(b);
-            }
+            if constexpr (GEO::shared_row(r)) finish_row<r>();
         });
-        return fail;                                                                  // non-zero bits = unsatisfied checks (:453)
+        return fail;
     }
 };
+
+// ---- prologue / epilogue pieces shared by the one-wave and the split drivers ----------------------------------------------
+// 2048 raw LLR bytes of one block column of the group (32 per lane, `src` = the lane's byte offset into llrs) -> staging slab at
+// LDS offset `stage` (2048 bytes) -> the lane's 8 bit planes X[p]: bit (index / L) of lane (q, index mod L) = bit p of the LLR.
+template <int CODE, class B, class D>
+BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, typename B::V src, typename B::V cw, typename B::V valid, int stage,
+                              typename B::V (&X)[8])
+{
+    using GEO = Geo<CODE>;
+    using V = typename B::V;
+    constexpr int M = GEO::M, L = GEO::L, Q = GEO::Q;
+    sfor<0, 8>([&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+        const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i)), valid), valid);
+        b.lds_write32(B::add(B::shl(d.lane, 5), B::c(stage + 4 * i)), w);
+    });
+    // lane (cw, q, ll) gathers the bytes of its 32 indices: q * Q + ll + L * bit; dword dd holds bits dd, 8 + dd, 16 + dd, 24 + dd
+    const V base = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), B::add(d.ll, B::c(stage)));
+    sfor<0, 8>([&](auto D_) {
+        constexpr int dd = decltype(D_)::value;
+        V x = b.lds_read_u8(B::add(base, B::c(L * dd)));
+        x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (8 + dd)))), 8));
+        x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (16 + dd)))), 16));
+        x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (24 + dd)))), 24));
+        X[dd] = x;
+    });
+    // 8 x 8 bit-matrix transpose inside every byte lane: afterwards X[p] byte y bit dd = bit p of LLR (8 y + dd)
+    auto stage_t = [&](auto S_, uint32_t mask) {
+        constexpr int s = decltype(S_)::value;
+        sfor<0, 8>([&](auto D_) {
+            constexpr int dd = decltype(D_)::value;
+            if constexpr ((dd & s) == 0) {
+                const V t = B::and_(B::xor_(B::shr(X[dd], s), X[dd + s]), B::c(mask));
+                X[dd + s] = B::xor_(X[dd + s], t);
+                X[dd] = B::xor_(X[dd], B::shl(t, s));
+            }
+        });
+    };
+    stage_t(IC<4>{}, 0x0F0F0F0Fu);
+    stage_t(IC<2>{}, 0x33333333u);
+    stage_t(IC<1>{}, 0x55555555u);
+}
+
+// the hard-decision plane of one block column (64 words at LDS offset `base`, one per lane) -> the lane's dword of 32 consecutive
+// output bits, MSB first inside each byte (decoder.rs:455-461)
+template <int CODE, class B, class D>
+BS_FN typename B::V pack_hard_column(B &b, const D &d, int base)
+{
+    using GEO = Geo<CODE>;
+    using V = typename B::V;
+    constexpr int L = GEO::L;
+    const V b0 = B::shl(d.ll, 5 - ilog2c(L));                                 // first bit of this lane's 32 indices: 32 ll / L
+    const V qbase = B::shl(B::add(d.cwbase, B::shl(d.q, ilog2c(L))), 2);     // byte offset of the quarter's first lane
+    V out = B::c(0);
+    sfor<0, L>([&](auto LL_) {
+        constexpr int l2 = decltype(LL_)::value;
+        const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(base + 4 * l2))), b0);
+        sfor<0, 32 / L>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            constexpr int t = l2 + L * k;                                     // index inside the 32, MSB first inside its byte
+            constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
+            out = B::or_(out, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
+        });
+    });
+    return out;
+}
 
 // once per kernel (per wave): the lane permutation tables
 template <int CODE, class B>
@@ -632,11 +677,11 @@ BS_FN void init_kernel(B &b)
 // (Lane offsets are relative to the group's first frame, so they fit 32 bits whatever the batch.)
 template <int CODE, class B>
 BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint32_t *iters_all, uint8_t *success_all, uint32_t batch,
-                        uint32_t maxiters, uint32_t group, uint32_t *ws = nullptr)
+                        uint32_t maxiters, uint32_t group)
 {
     using GEO = Geo<CODE>;
     using V = typename B::V;
-    constexpr int M = GEO::M, N = GEO::N, L = GEO::L, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS, Q = GEO::Q;
+    constexpr int M = GEO::M, N = GEO::N, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS;
     Decoder<CODE, B> d;
     d.init_lane(b);
     const V lane = d.lane;
@@ -654,94 +699,60 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     sfor<0, NTX>([&](auto C_) {
         constexpr int c = decltype(C_)::value;
         const V src = B::add(B::mul_u(frame, (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));        // byte offset into llrs (batch * N < 2^32: launcher)
-        sfor<0, 8>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i)), valid), valid);
-            b.lds_write32(B::add(B::shl(lane, 5), B::c(GEO::LDS_STAGE + 4 * i)), w);
-        });
-        // lane (cw, q, ll) gathers the bytes of its 32 indices: q * Q + ll + L * bit; dword dd holds bits dd, 8 + dd, 16 + dd, 24 + dd
-        const V base = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), B::add(d.ll, B::c(GEO::LDS_STAGE)));
         V X[8];
-        sfor<0, 8>([&](auto D_) {
-            constexpr int dd = decltype(D_)::value;
-            V x = b.lds_read_u8(B::add(base, B::c(L * dd)));
-            x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (8 + dd)))), 8));
-            x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (16 + dd)))), 16));
-            x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (24 + dd)))), 24));
-            X[dd] = x;
-        });
-        // 8 x 8 bit-matrix transpose inside every byte lane: afterwards X[p] byte y bit dd = bit p of LLR (8 y + dd)
-        auto stage = [&](auto S_, uint32_t mask) {
-            constexpr int s = decltype(S_)::value;
-            sfor<0, 8>([&](auto D_) {
-                constexpr int dd = decltype(D_)::value;
-                if constexpr ((dd & s) == 0) {
-                    const V t = B::and_(B::xor_(B::shr(X[dd], s), X[dd + s]), B::c(mask));
-                    X[dd + s] = B::xor_(X[dd + s], t);
-                    X[dd] = B::xor_(X[dd], B::shl(t, s));
-                }
-            });
-        };
-        stage(IC<4>{}, 0x0F0F0F0Fu);
-        stage(IC<2>{}, 0x33333333u);
-        stage(IC<1>{}, 0x55555555u);
+        load_column_planes<CODE>(b, d, llrs, src, cw, valid, GEO::LDS_STAGE, X);
         sfor<0, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            if constexpr (GEO::LLR_GLOBAL) b.gstore32(ws, B::add(B::shl(lane, 2), B::c((c * 8 + k) * 256)), X[k], B::c(0xFFFFFFFFu));
-            else b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);
+            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);
         });
     });
 
-    d.reset_state(b);                  // (after the LLRs: row 0's LDS state aliases the staging slab)
+    d.reset_state(b);                  // (after the LLRs: the hard-decision words alias the staging slab)
     d.prime_perm(b);
 
     // ---- iterations (decoder.rs:380-464): the codewords of the wave run in lockstep, a finished one is frozen ----
     uint64_t frozen_mask = ~valid_mask;
     V iters_v = B::c(maxiters), ok_v = B::c(0);
+    uint32_t iters_s = maxiters, ok_s = 0;                                     // (W = 64: one codeword, the verdict is wave-uniform)
     for (uint32_t it = 0; it < maxiters && frozen_mask != ~0ull; ++it) {
         const V frozen = b.plane_of(frozen_mask);
-        const V fail = d.iteration(b, frozen, ws);
+        const V fail = d.iteration(b, frozen);
         const uint64_t unsat_lanes = b.ballot(fail);
-        uint64_t unsat = 0;
-        if constexpr (W == 64) unsat = unsat_lanes ? ~0ull : 0ull;
-        else {
+        if constexpr (W == 64) {
+            if (unsat_lanes == 0) { iters_s = it; ok_s = 1; frozen_mask = ~0ull; }   // satisfied: (true, it)  (:453-463)
+        } else {
+            uint64_t unsat = 0;
             constexpr uint64_t gm = (1ull << W) - 1;
             for (int g = 0; g < G; ++g)
                 if ((unsat_lanes >> (g * W)) & gm) unsat |= gm << (g * W);
+            const uint64_t newly = ~frozen_mask & ~unsat;                      // satisfied for the first time: (true, it)  (:453-463)
+            const V nw = b.plane_of(newly);
+            iters_v = B::template bitop3<TT_MUX>(nw, B::c(it), iters_v);
+            ok_v = B::or_(ok_v, B::and_(nw, B::c(1)));
+            frozen_mask |= newly;
         }
-        const uint64_t newly = ~frozen_mask & ~unsat;                          // satisfied for the first time: (true, it)  (:453-463)
-        const V nw = b.plane_of(newly);
-        iters_v = B::template bitop3<TT_MUX>(nw, B::c(it), iters_v);
-        ok_v = B::or_(ok_v, B::and_(nw, B::c(1)));
-        frozen_mask |= newly;
     }
+    if constexpr (W == 64) { iters_v = B::c(iters_s); ok_v = B::c(ok_s); }
 
     // ---- hard decisions, MSB first (decoder.rs:455-461 / :467-473): plane -> LDS -> one dword of 32 consecutive bits per lane ----
     if constexpr (!GEO::HARD_LDS)
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
-            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c * 256)), d.hard[c]);
+            b.lds_write32(d.hard_addr(c), d.hard[c]);
         });
-    const V b0 = B::shl(d.ll, 5 - ilog2c(L));                                 // first bit of this lane's 32 indices: 32 ll / L
-    const V qbase = B::shl(B::add(d.cwbase, B::shl(d.q, ilog2c(L))), 2);     // byte offset of the quarter's first lane
+    // (the lane constants are formed again from an opaque copy of the lane index: as common subexpressions of the prologue's they would
+    // hold half a dozen registers through the iteration loop)
+    d.reinit_lane();
+    const V cw2 = B::shr(d.lane, ilog2c(W)), lw2 = B::and_(d.lane, B::c(W - 1));
+    const V valid2 = B::less_u(B::add(B::c(group * (uint32_t)G), cw2), B::c(batch));
     sfor<0, NCOLS>([&](auto C_) {
         constexpr int c = decltype(C_)::value;
-        V out = B::c(0);
-        sfor<0, L>([&](auto LL_) {
-            constexpr int l2 = decltype(LL_)::value;
-            const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(GEO::LDS_HARD + c * 256 + 4 * l2))), b0);
-            sfor<0, 32 / L>([&](auto K_) {
-                constexpr int k = decltype(K_)::value;
-                constexpr int t = l2 + L * k;                                     // index inside the 32, MSB first inside its byte
-                constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
-                out = B::or_(out, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
-            });
-        });
-        b.gstore32(output, B::add(B::mul_u(frame, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw, 2))), out, valid);
+        const V out = pack_hard_column<CODE>(b, d, GEO::LDS_HARD + GEO::col_slot(c) * 256);
+        b.gstore32(output, B::add(B::mul_u(cw2, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw2, 2))), out, valid2);
     });
-    const V first = B::and_(valid, B::eq(lw, B::c(0)));
-    b.gstore32(iters, B::shl(frame, 2), iters_v, first);
-    b.gstore8(success, frame, ok_v, first);
+    const V first = B::and_(valid2, B::eq(lw2, B::c(0)));
+    b.gstore32(iters, B::shl(cw2, 2), iters_v, first);
+    b.gstore8(success, cw2, ok_v, first);
 }
 
 }  // namespace bs

@@ -81,35 +81,8 @@ struct SplitGroup {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) {
                 const V src = B::add(B::mul_u(frame, (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));
-                sfor<0, 8>([&](auto I_) {
-                    constexpr int i = decltype(I_)::value;
-                    const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i)), valid), valid);
-                    b.lds_write32(B::add(B::shl(lane, 5), B::c(XO + 4 * i)), w);
-                });
-                const V base = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), B::add(d.ll, B::c(XO)));
                 V X[8];
-                sfor<0, 8>([&](auto D_) {
-                    constexpr int dd = decltype(D_)::value;
-                    V x = b.lds_read_u8(B::add(base, B::c(L * dd)));
-                    x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (8 + dd)))), 8));
-                    x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (16 + dd)))), 16));
-                    x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (24 + dd)))), 24));
-                    X[dd] = x;
-                });
-                auto stage = [&](auto S_, uint32_t mask) {
-                    constexpr int s = decltype(S_)::value;
-                    sfor<0, 8>([&](auto D_) {
-                        constexpr int dd = decltype(D_)::value;
-                        if constexpr ((dd & s) == 0) {
-                            const V t = B::and_(B::xor_(B::shr(X[dd], s), X[dd + s]), B::c(mask));
-                            X[dd + s] = B::xor_(X[dd + s], t);
-                            X[dd] = B::xor_(X[dd], B::shl(t, s));
-                        }
-                    });
-                };
-                stage(IC<4>{}, 0x0F0F0F0Fu);
-                stage(IC<2>{}, 0x33333333u);
-                stage(IC<1>{}, 0x55555555u);
+                load_column_planes<CODE>(b, d, llrs, src, cw, valid, XO, X);       // (the staging slab is this wave's exchange buffer)
                 sfor<0, 8>([&](auto K_) {
                     constexpr int k = decltype(K_)::value;
                     b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)), X[k]);
@@ -130,8 +103,7 @@ struct SplitGroup {
     BS_FN void stage_columns(B &b)
     {
         const V frozen = b.plane_of(frozen_mask);
-        d.begin_iteration(b);
-        d.columns(b, frozen, nullptr);
+        d.columns(b, frozen);              // (the rows only this wave has edges in are finished in there: d.fail)
     }
     static BS_FN V xaddr(V lane, int base, int plane) { return B::add(B::shl(lane, 2), B::c(base + plane * 256)); }
 
@@ -158,12 +130,7 @@ struct SplitGroup {
     BS_FN void stage_publish(B &b)
     {
         put_row<PUB>(b, XO);
-        V own = B::c(0);
-        sfor<0, NROWS>([&](auto R2_) {
-            constexpr int r2 = decltype(R2_)::value;
-            if constexpr (GEO::has_row(r2) && !GEO::shared_row(r2)) own = B::or_(own, d.Pn[r2]);
-        });
-        b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), own);
+        b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), d.fail);
     }
 
     // ---- stage 3: the other wave's partial state of row MRG (in ITS buffer) merged into this wave's; the result goes back into that
@@ -240,22 +207,10 @@ struct SplitGroup {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_HARD + c_slot(c) * 256)), d.hard[c]);
         });
-        const V b0 = B::shl(d.ll, 5 - ilog2c(L));
-        const V qbase = B::shl(B::add(d.cwbase, B::shl(d.q, ilog2c(L))), 2);
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) {
-                V out = B::c(0);
-                sfor<0, L>([&](auto LL_) {
-                    constexpr int l2 = decltype(LL_)::value;
-                    const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(GEO::LDS_HARD + c_slot(c) * 256 + 4 * l2))), b0);
-                    sfor<0, 32 / L>([&](auto K_) {
-                        constexpr int k = decltype(K_)::value;
-                        constexpr int t = l2 + L * k;
-                        constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
-                        out = B::or_(out, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
-                    });
-                });
+                const V out = pack_hard_column<CODE>(b, d, GEO::LDS_HARD + c_slot(c) * 256);
                 b.gstore32(output, B::add(B::mul_u(frame, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw, 2))), out, valid);
             }
         });

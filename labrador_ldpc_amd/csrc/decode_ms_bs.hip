@@ -1,59 +1,39 @@
 // decode_ms_bs.hip -- gfx950 instantiation of the bit-sliced i8 min-sum decoder (decode_ms_bitslice.hpp;
 // decode_ms::<i8>, /root/reference/src/decoder.rs:42-50, :347-475) for the TM codes, and its launcher.
 //
-// One wave per workgroup, one group of G = 64 / (M/32) codewords per wave at a time: a codeword never leaves its wave, so the
-// kernel has no barrier.  Rate 1/2 and 2/3: one group per workgroup -- the hardware dispatcher is the work queue (decodes take
-// 3..25 iterations; a finished wave makes room for the next group at once); LDS per workgroup: the LLRs as bit planes (n bytes per
-// codeword, the size of the raw LLRs), a 2 KB staging slab, the lane-permutation table, one word per lane and block column for
-// the hard decisions.  Rate 4/5: persistent waves (the resident set), each with a 20 KB slot of a stream-ordered global
-// workspace for its LLR planes, groups drawn from a queue head at the start of that workspace (decode_ms_bitslice.hpp, "register diet").
+// Rate 1/2 and 2/3: one wave per workgroup, one group of G = 64 / (M/32) codewords per wave at a time -- a codeword never leaves its
+// wave, so the kernel has no barrier; one group per workgroup: the hardware dispatcher is the work queue (decodes take 3..25
+// iterations; a finished wave makes room for the next group at once).  LDS per workgroup: the LLRs as bit planes (n bytes per
+// codeword, the size of the raw LLRs), the lane-permutation table, one word per lane and block column for the hard decisions (which
+// doubles as the staging slab of the LLR transposition).  Rate 4/5: a group shared by the two waves of a workgroup
+// (decode_ms_bitslice_split.hpp).
 #include <hip/hip_runtime.h>
-#include <atomic>
 #include <cstdint>
 
 #include "decode_ms_bitslice.hpp"
 #include "decode_ms_bitslice_split.hpp"
 #include "hip_backend.hpp"
 
-#if defined(BS_DIAG) && !defined(BS_DIAG_BUILD)
-#error "BS_DIAG builds decode wrongly: only tools/bs_diag_build.sh may define it"
-#endif
-
 namespace ldpc {
 namespace bs {
 
-
-// waves per SIMD the kernel is compiled for: two for every code (256 registers).  The rate-1/2 and rate-2/3 codes hold a group of
-// codewords in that; the rate-4/5 codes' state (39 edges: ~250 planes before any temporary) is put on the "register diet" of
-// decode_ms_bitslice.hpp to fit -- one wave per SIMD with everything in registers measured 23.4 against 33.3 M codewords/s (TM5120)
-template <int CODE> constexpr int waves_per_simd() { return 2; }
-
-constexpr int WS_HEADER_WORDS = 64;          // the queue head, on a 256-byte line of its own
+// waves per SIMD the kernel is compiled for.  Rate 1/2 (TM2048, TM8192): THREE -- 168 registers -- since round 5: a row's running
+// state replaces its old state with the row's last edge, block row 0 finishes first, the hard decisions live in LDS
+// (decode_ms_bitslice.hpp, "schedule of an iteration").  Rate 2/3: two (256 registers).
+#ifndef BS_WAVES_R12
+#define BS_WAVES_R12 3
+#endif
+template <int CODE> constexpr int waves_per_simd() { return (CODE == TM2048 || CODE == TM8192) ? BS_WAVES_R12 : 2; }
 
 template <int CODE>
 __global__ void __launch_bounds__(64, waves_per_simd<CODE>())
 decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters,
-                    uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t ngroups, uint32_t *__restrict__ workspace)
+                    uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t ngroups)
 {
     __shared__ __attribute__((aligned(16))) char lds[Geo<CODE>::LDS_BYTES];
     HipBackend b{lds};
     init_kernel<CODE, HipBackend>(b);
-    if constexpr (Geo<CODE>::LLR_GLOBAL) {
-        // persistent waves, fed from a queue: the workspace starts with the queue head (zeroed by the launcher), this wave's slot of LLR
-        // planes follows.  A wave's first group is its own index; every further one is drawn with one atomic.  (A fixed stride lost 7-14 %
-        // even where every frame takes the same 25 iterations -- the waves of a CU do not run at one speed -- and 40 % on a box whose
-        // chip was unevenly clocked: profiles/r04_kbench/r45_queue_ab.txt.)
-        uint32_t *ws = workspace + WS_HEADER_WORDS + (size_t)blockIdx.x * Geo<CODE>::LLR_WORDS;
-        uint32_t g = blockIdx.x;
-        while (g < ngroups) {
-            decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g, ws);
-            uint32_t t = 0;
-            if ((threadIdx.x & 63) == 0) t = atomicAdd(workspace, 1u);
-            g = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        }
-    } else {
-        for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g, nullptr);
-    }
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g);
 }
 
 // ---- the rate-4/5 codes: a group of codewords shared by the two waves of a workgroup (decode_ms_bitslice_split.hpp).  One group per
@@ -99,35 +79,10 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
     if (batch == 0) return hipSuccess;
     if (batch > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const size_t groups = (batch + G - 1) / G;
-    size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
-    uint32_t *ws = nullptr;
-    if constexpr (Geo<CODE>::LLR_GLOBAL) {
-        // persistent waves, one workspace slot each: the grid is the resident set, the groups are drawn from a queue (kernel)
-        static std::atomic<int> cached[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        int resident = cached[dev].load(std::memory_order_relaxed);
-        if (resident == 0) {
-            int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_bs_kernel<CODE>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-            resident = per_cu * cus;
-            cached[dev].store(resident, std::memory_order_relaxed);
-        }
-        if (grid > (size_t)resident) grid = (size_t)resident;
-        hipError_t e = hipMallocAsync((void **)&ws, (WS_HEADER_WORDS + grid * Geo<CODE>::LLR_WORDS) * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(ws, 0, WS_HEADER_WORDS * sizeof(uint32_t), stream);
-        if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return e; }
-    }
+    const size_t grid = groups < 0x7FFFFFFFull ? groups : 0x7FFFFFFFull;
     hipLaunchKernelGGL((decode_ms_bs_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
-                       (uint32_t)groups, ws);
-    hipError_t e = hipGetLastError();
-    if (ws != nullptr) {
-        const hipError_t e2 = hipFreeAsync(ws, stream);
-        if (e == hipSuccess) e = e2;
-    }
-    return e;
+                       (uint32_t)groups);
+    return hipGetLastError();
 }
 
 }  // namespace bs
@@ -149,10 +104,10 @@ hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *out
                                       uint32_t maxiters, hipStream_t stream)
 {
     switch (code) {
-        case TM1280: return bs::launch<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
         case TM1536: return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
         case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
-        case TM5120: return bs::launch<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
         case TM6144: return bs::launch<TM6144>(llrs, output, iters, success, batch, maxiters, stream);
         case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
         default: return hipErrorInvalidConfiguration;

@@ -95,8 +95,7 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
     for (size_t g = 0; g < groups; ++g) {
         EmuBackend b(GEO::LDS_BYTES);
         ldpc::bs::init_kernel<CODE, EmuBackend>(b);
-        std::vector<uint32_t> ws(GEO::LLR_GLOBAL ? GEO::LLR_WORDS : 1, 0xA5A5A5A5u);      // the wave's slot of the LLR workspace
-        ldpc::bs::decode_group<CODE, EmuBackend>(b, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g, ws.data());
+        ldpc::bs::decode_group<CODE, EmuBackend>(b, llrs, out, iters, ok, (uint32_t)batch, maxiters, (uint32_t)g);
     }
     return 0;
 }
@@ -140,7 +139,9 @@ int run_split(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, si
 #endif
 extern "C" int bs_emu_decode(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
 {
-    return run<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+    // (the rate-4/5 codes exist only in the two-waves-per-group form)
+    if constexpr (ldpc::bs::Geo<ldpc::EMU_CODE>::TWO_WAVES) return run_split<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+    else return run<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
 }
 extern "C" int bs_emu_decode_bf(const uint8_t *input, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
 {
@@ -155,7 +156,7 @@ extern "C" int bs_emu_decode_bf(const uint8_t *input, uint8_t *out, uint32_t *it
 }
 extern "C" int bs_emu_decode_split(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
 {
-    if constexpr (ldpc::bs::Geo<ldpc::EMU_CODE>::LLR_GLOBAL) return run_split<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+    if constexpr (ldpc::bs::Geo<ldpc::EMU_CODE>::TWO_WAVES) return run_split<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
     else return -1;                                                     // rate 4/5 only
 }
 extern "C" int bs_emu_group(void) { return ldpc::bs::Geo<ldpc::EMU_CODE>::G; }
