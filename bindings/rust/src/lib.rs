@@ -119,6 +119,11 @@ extern "C" {
     pub fn labrador_ldpc_decode_ms_batch_i16(code: LDPCCode, llrs: *const i16, output: *mut u8, iters: *mut u32, success: *mut u8, batch: usize, max_iters: usize, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_decode_ms_batch_i32(code: LDPCCode, llrs: *const i32, output: *mut u8, iters: *mut u32, success: *mut u8, batch: usize, max_iters: usize, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_decode_ms_batch_f64(code: LDPCCode, llrs: *const f64, output: *mut u8, iters: *mut u32, success: *mut u8, batch: usize, max_iters: usize, opts: *const HipOpts) -> c_int;
+    pub fn labrador_ldpc_decode_ms_batch_f32_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const f32, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int;
+    pub fn labrador_ldpc_decode_ms_batch_i8_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const i8, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int;
+    pub fn labrador_ldpc_decode_ms_batch_i16_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const i16, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int;
+    pub fn labrador_ldpc_decode_ms_batch_i32_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const i32, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int;
+    pub fn labrador_ldpc_decode_ms_batch_f64_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const f64, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int;
     pub fn labrador_ldpc_decode_bf_batch(code: LDPCCode, input: *const u8, output: *mut u8, iters: *mut u32, success: *mut u8, batch: usize, max_iters: usize, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_encode_batch(code: LDPCCode, data: *const u8, codewords: *mut u8, batch: usize, opts: *const HipOpts) -> c_int;
     pub fn labrador_ldpc_hard_to_llrs_batch_i8(code: LDPCCode, input: *const u8, llrs: *mut i8, batch: usize, opts: *const HipOpts) -> c_int;
@@ -143,6 +148,7 @@ extern "C" {
     pub fn labrador_ldpc_hip_version() -> *const c_char;
     pub fn labrador_ldpc_hip_build_id() -> *const c_char;
     pub fn labrador_ldpc_hip_abi_version() -> c_int;
+    pub fn labrador_ldpc_hip_decode_ms_i8_kernel(code: LDPCCode, variant: c_int, batch: usize) -> *const c_char;
 }
 
 /// The calling thread's last failure ("" if none).
@@ -159,18 +165,32 @@ pub fn abi_matches() -> bool {
 pub trait DecodeFrom: Copy {
     unsafe fn decode_ms(code: LDPCCode, llrs: *const Self, output: *mut u8, working: *mut Self, working_u8: *mut u8, max_iters: usize, iters_run: *mut usize) -> bool;
     unsafe fn decode_ms_batch(code: LDPCCode, llrs: *const Self, output: *mut u8, iters: *mut u32, success: *mut u8, batch: usize, max_iters: usize, opts: *const HipOpts) -> c_int;
+    unsafe fn decode_ms_batch_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const Self, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int;
     unsafe fn hard_to_llrs(code: LDPCCode, input: *const u8, llrs: *mut Self);
     unsafe fn llrs_to_hard(code: LDPCCode, llrs: *const Self, output: *mut u8);
 }
 
+/// One device-resident batch of a multi-GPU decode: `frames` frames whose four buffers live on HIP device `device`.
+pub struct DevicePart<T> {
+    pub device: c_int,
+    pub llrs: *const T,
+    pub output: *mut u8,
+    pub iters: *mut u32,
+    pub success: *mut u8,
+    pub frames: usize,
+}
+
 macro_rules! decode_from {
-    ($t:ty, $ms:ident, $batch:ident, $h2l:ident, $l2h:ident) => {
+    ($t:ty, $ms:ident, $batch:ident, $multi:ident, $h2l:ident, $l2h:ident) => {
         impl DecodeFrom for $t {
             unsafe fn decode_ms(code: LDPCCode, llrs: *const Self, output: *mut u8, working: *mut Self, working_u8: *mut u8, max_iters: usize, iters_run: *mut usize) -> bool {
                 $ms(code, llrs, output, working, working_u8, max_iters, iters_run)
             }
             unsafe fn decode_ms_batch(code: LDPCCode, llrs: *const Self, output: *mut u8, iters: *mut u32, success: *mut u8, batch: usize, max_iters: usize, opts: *const HipOpts) -> c_int {
                 $batch(code, llrs, output, iters, success, batch, max_iters, opts)
+            }
+            unsafe fn decode_ms_batch_multi(code: LDPCCode, n_parts: usize, devices: *const c_int, llrs: *const *const Self, output: *const *mut u8, iters: *const *mut u32, success: *const *mut u8, frames: *const usize, max_iters: usize, variant: c_int) -> c_int {
+                $multi(code, n_parts, devices, llrs, output, iters, success, frames, max_iters, variant)
             }
             unsafe fn hard_to_llrs(code: LDPCCode, input: *const u8, llrs: *mut Self) {
                 $h2l(code, input, llrs)
@@ -181,11 +201,11 @@ macro_rules! decode_from {
         }
     };
 }
-decode_from!(i8, labrador_ldpc_decode_ms_i8, labrador_ldpc_decode_ms_batch_i8, labrador_ldpc_hard_to_llrs_i8, labrador_ldpc_llrs_to_hard_i8);
-decode_from!(i16, labrador_ldpc_decode_ms_i16, labrador_ldpc_decode_ms_batch_i16, labrador_ldpc_hard_to_llrs_i16, labrador_ldpc_llrs_to_hard_i16);
-decode_from!(i32, labrador_ldpc_decode_ms_i32, labrador_ldpc_decode_ms_batch_i32, labrador_ldpc_hard_to_llrs_i32, labrador_ldpc_llrs_to_hard_i32);
-decode_from!(f32, labrador_ldpc_decode_ms_f32, labrador_ldpc_decode_ms_batch_f32, labrador_ldpc_hard_to_llrs_f32, labrador_ldpc_llrs_to_hard_f32);
-decode_from!(f64, labrador_ldpc_decode_ms_f64, labrador_ldpc_decode_ms_batch_f64, labrador_ldpc_hard_to_llrs_f64, labrador_ldpc_llrs_to_hard_f64);
+decode_from!(i8, labrador_ldpc_decode_ms_i8, labrador_ldpc_decode_ms_batch_i8, labrador_ldpc_decode_ms_batch_i8_multi, labrador_ldpc_hard_to_llrs_i8, labrador_ldpc_llrs_to_hard_i8);
+decode_from!(i16, labrador_ldpc_decode_ms_i16, labrador_ldpc_decode_ms_batch_i16, labrador_ldpc_decode_ms_batch_i16_multi, labrador_ldpc_hard_to_llrs_i16, labrador_ldpc_llrs_to_hard_i16);
+decode_from!(i32, labrador_ldpc_decode_ms_i32, labrador_ldpc_decode_ms_batch_i32, labrador_ldpc_decode_ms_batch_i32_multi, labrador_ldpc_hard_to_llrs_i32, labrador_ldpc_llrs_to_hard_i32);
+decode_from!(f32, labrador_ldpc_decode_ms_f32, labrador_ldpc_decode_ms_batch_f32, labrador_ldpc_decode_ms_batch_f32_multi, labrador_ldpc_hard_to_llrs_f32, labrador_ldpc_llrs_to_hard_f32);
+decode_from!(f64, labrador_ldpc_decode_ms_f64, labrador_ldpc_decode_ms_batch_f64, labrador_ldpc_decode_ms_batch_f64_multi, labrador_ldpc_hard_to_llrs_f64, labrador_ldpc_llrs_to_hard_f64);
 
 impl LDPCCode {
     pub fn n(self) -> usize { unsafe { labrador_ldpc_code_n(self) } }
@@ -253,6 +273,20 @@ impl LDPCCode {
         }
         let o = opts.map_or(core::ptr::null(), |o| o as *const HipOpts);
         let st = unsafe { T::decode_ms_batch(self, llrs.as_ptr(), output.as_mut_ptr(), iters.as_mut_ptr(), success.as_mut_ptr(), batch, maxiters, o) };
+        if st == OK { Ok(()) } else { Err(st) }
+    }
+
+    /// Device-resident batches on several GPUs with ONE call (the reference harness's shape: one job over all workers,
+    /// perftest/src/main.rs:39-52): every part is enqueued by the library's worker of its device; returns when all are decoded.
+    /// Unsafe: the pointers are device memory the caller vouches for.
+    pub unsafe fn decode_ms_batch_multi<T: DecodeFrom>(self, parts: &[DevicePart<T>], maxiters: usize, variant: c_int) -> Result<(), c_int> {
+        let devices: Vec<c_int> = parts.iter().map(|p| p.device).collect();
+        let llrs: Vec<*const T> = parts.iter().map(|p| p.llrs).collect();
+        let output: Vec<*mut u8> = parts.iter().map(|p| p.output).collect();
+        let iters: Vec<*mut u32> = parts.iter().map(|p| p.iters).collect();
+        let success: Vec<*mut u8> = parts.iter().map(|p| p.success).collect();
+        let frames: Vec<usize> = parts.iter().map(|p| p.frames).collect();
+        let st = T::decode_ms_batch_multi(self, parts.len(), devices.as_ptr(), llrs.as_ptr(), output.as_ptr(), iters.as_ptr(), success.as_ptr(), frames.as_ptr(), maxiters, variant);
         if st == OK { Ok(()) } else { Err(st) }
     }
 

@@ -249,13 +249,29 @@ struct labrador_ldpc_hip_opts {
     void *stream;     /* hipStream_t to launch on; NULL = the default stream.  With MEM_DEVICE
                          the call only enqueues work and returns (asynchronous); with MEM_HOST
                          it returns after the results are in the host buffers. */
-    int   variant;    /* kernel variant; 0 = the tuned default (others: see DESIGN.md / INTEGRATION.md; flags that may be
-                         OR-ed in: 256 = fixed-stride distribution of the codewords, 512 / 1024 = one / two launches for
-                         the NaN handling of TM5120 / TM1280 f32).  Every variant returns identical results. */
+    int   variant;    /* enum labrador_ldpc_hip_variant below; 0 = the tuned default.  Every variant returns identical results. */
     int   n_devices;  /* > 0: shard a MEM_HOST batch over devices[0 .. n_devices) (`device` is ignored) */
     const int *devices; /* HIP ordinals; an ordinal may repeat (that many host pipelines on it) */
 };
 #define LABRADOR_LDPC_HIP_OPTS_INIT { sizeof(struct labrador_ldpc_hip_opts) }
+
+/* `variant`: which of the library's decode_ms kernels a batched call runs.  0 is what callers want; the others exist so that the
+ * tuned choice can be A/B-ed against its alternatives (all return identical results; a value that was not built for the code and
+ * LLR type yields LABRADOR_LDPC_HIP_EUNSUPPORTED).  One kernel value, optionally OR-ed with flags. */
+enum labrador_ldpc_hip_variant {
+    LABRADOR_LDPC_HIP_VARIANT_DEFAULT       = 0,    /* the tuned kernel for (code, LLR type, batch size) */
+    LABRADOR_LDPC_HIP_VARIANT_IPT1          = 1,    /* f32-pipe kernel (messages as f32 / f64 / i32 registers), one index per thread */
+    LABRADOR_LDPC_HIP_VARIANT_IPT2          = 2,    /* ... two indices per thread (t, t + M/2) */
+    LABRADOR_LDPC_HIP_VARIANT_IPT4          = 4,    /* ... four */
+    LABRADOR_LDPC_HIP_VARIANT_LEAN          = 16,   /* OR-ed with IPTn: the register-lean check phase (one check row at a time) */
+    LABRADOR_LDPC_HIP_VARIANT_PAIR          = 32,   /* adjacent-index pair ownership (TM8192, TM2048); f64: OR-ed with IPTn = in-place messages */
+    LABRADOR_LDPC_HIP_VARIANT_BITSLICE      = 64,   /* i8 LLRs, TM codes: the bit-sliced kernel whatever the batch size */
+    LABRADOR_LDPC_HIP_VARIANT_F64_WORKSPACE = 100,  /* f64: the general kernel with its messages in a device workspace */
+    /* flags */
+    LABRADOR_LDPC_HIP_VARIANT_STATIC        = 256,  /* fixed-stride distribution of the codewords instead of the launch's queue */
+    LABRADOR_LDPC_HIP_VARIANT_NAN_ONE_PASS  = 512,  /* TM5120 / TM1280 f32: NaN LLRs handled inside the one kernel ... */
+    LABRADOR_LDPC_HIP_VARIANT_NAN_TWO_PASS  = 1024  /* ... or by a second launch over marked codewords (the default from ~1000 frames) */
+};
 
 /* Multi-GPU (the reference's analogue is perftest/src/main.rs:39-45, one worker per
  * core over independent frames): with MEM_HOST buffers and a device set -- `device` ==
@@ -292,6 +308,30 @@ int labrador_ldpc_decode_ms_batch_i32(enum labrador_ldpc_code code, const int32_
 int labrador_ldpc_decode_ms_batch_f64(enum labrador_ldpc_code code, const double *llrs, uint8_t *output,
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
+
+/* Device-resident batches on SEVERAL GPUs with one call (the reference's analogue: one job over all workers,
+ * perftest/src/main.rs:39-52; capi/src/lib.rs:83-95 for the buffers' meaning).  Part i is frames[i] frames whose four buffers --
+ * llrs[i], output[i] (8-byte aligned), iters[i], success[i], laid out as in labrador_ldpc_decode_ms_batch_* -- are DEVICE memory
+ * resident on HIP device devices[i]; an ordinal may repeat (several parts on one GPU) and frames[i] may be 0.  Every part is
+ * enqueued by the library's persistent worker thread of its device (pinned to the GPU's NUMA node) on a stream of the library's own
+ * and the call returns when ALL parts are decoded; work the caller enqueued on its own streams for these buffers must be complete
+ * before the call.  No data crosses between devices and there is no collective.  Returns the first failing part's status
+ * (labrador_ldpc_hip_last_error() names the part and its device). */
+int labrador_ldpc_decode_ms_batch_f32_multi(enum labrador_ldpc_code code, size_t n_parts, const int *devices, const float *const *llrs,
+                                            uint8_t *const *output, uint32_t *const *iters, uint8_t *const *success,
+                                            const size_t *frames, size_t max_iters, int variant);
+int labrador_ldpc_decode_ms_batch_i8_multi (enum labrador_ldpc_code code, size_t n_parts, const int *devices, const int8_t *const *llrs,
+                                            uint8_t *const *output, uint32_t *const *iters, uint8_t *const *success,
+                                            const size_t *frames, size_t max_iters, int variant);
+int labrador_ldpc_decode_ms_batch_i16_multi(enum labrador_ldpc_code code, size_t n_parts, const int *devices, const int16_t *const *llrs,
+                                            uint8_t *const *output, uint32_t *const *iters, uint8_t *const *success,
+                                            const size_t *frames, size_t max_iters, int variant);
+int labrador_ldpc_decode_ms_batch_i32_multi(enum labrador_ldpc_code code, size_t n_parts, const int *devices, const int32_t *const *llrs,
+                                            uint8_t *const *output, uint32_t *const *iters, uint8_t *const *success,
+                                            const size_t *frames, size_t max_iters, int variant);
+int labrador_ldpc_decode_ms_batch_f64_multi(enum labrador_ldpc_code code, size_t n_parts, const int *devices, const double *const *llrs,
+                                            uint8_t *const *output, uint32_t *const *iters, uint8_t *const *success,
+                                            const size_t *frames, size_t max_iters, int variant);
 
 /* Batched bit-flipping decoder (src/decoder.rs:243-301), the batched form of
  * labrador_ldpc_decode_bf:  input [batch][n/8], output [batch][output_len], iters [batch]
@@ -387,6 +427,12 @@ const char *labrador_ldpc_hip_version(void);
  * bytes, which hipcc does not reproduce bit for bit.  Two builds of one source tree report one id; any source or flag edit
  * changes it.  Profiles record the id they were collected on (profiles/hbm_traffic.json, bench.py). */
 const char *labrador_ldpc_hip_build_id(void);
+
+/* Name of the kernel labrador_ldpc_decode_ms_batch_i8 launches for a 4-byte-aligned device batch of `batch` frames with this
+ * `variant` ("decode_ms_bs_kernel" / "decode_ms_bs_split_kernel": bit-sliced; "decode_ms_pair_kernel" /
+ * "decode_ms_kernel": the f32-pipe kernels) -- the default dispatch depends on the batch size; harnesses label their
+ * measurements with it.  "" for a bad code. */
+const char *labrador_ldpc_hip_decode_ms_i8_kernel(enum labrador_ldpc_code code, int variant, size_t batch);
 
 /* The LABRADOR_LDPC_HIP_ABI the loaded library was built with: a client that dlopen()s the library compares it with its
  * own header's before passing a struct labrador_ldpc_hip_opts. */

@@ -78,6 +78,7 @@ SYMBOLS = {
     "labrador_ldpc_decode_ms_batch_i16": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_i32": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_decode_ms_batch_f64": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
+    **{f"labrador_ldpc_decode_ms_batch_{t}_multi": (_int, [_int, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int]) for t in ("i8", "i16", "i32", "f32", "f64")},
     "labrador_ldpc_decode_bf_batch": (_int, [_int, _vp, _vp, _vp, _vp, _sz, _sz, _optp]),
     "labrador_ldpc_encode_batch": (_int, [_int, _vp, _vp, _sz, _optp]),
     **{f"labrador_ldpc_hard_to_llrs_batch_{t}": (_int, [_int, _vp, _vp, _sz, _optp]) for t in ("i8", "i16", "i32", "f32", "f64")},
@@ -96,6 +97,7 @@ SYMBOLS = {
     "labrador_ldpc_hip_version": (_c.c_char_p, []),
     "labrador_ldpc_hip_build_id": (_c.c_char_p, []),
     "labrador_ldpc_hip_abi_version": (_int, []),
+    "labrador_ldpc_hip_decode_ms_i8_kernel": (_c.c_char_p, [_int, _int, _sz]),
 }
 
 
@@ -384,6 +386,33 @@ class LDPCCode(enum.IntEnum):
                   ctypes.byref(opts)))
         del keep
         return output, iters, success
+
+    def decode_ms_batch_multi(self, parts, maxiters: int = 50, variant: int = 0):
+        """Decode several device-resident batches -- one torch CUDA tensor `llrs[frames_i, n]` per part, each on its own (or the
+        same) GPU -- with ONE call: every part is enqueued by the library's worker of its device and the call returns when all
+        results are in place (labrador_ldpc_decode_ms_batch_*_multi; the reference's harness shape, one job over all workers,
+        perftest/src/main.rs:39-52).  Returns a list of (output, iters, success) tensors, one triple per part."""
+        import torch
+        parts = list(parts)
+        if not parts:
+            return []
+        if not all(_is_torch(p) and p.is_cuda and p.is_contiguous() and p.ndim == 2 and p.shape[1] == self.n() for p in parts):
+            raise ValueError("every part must be a contiguous torch CUDA tensor [frames, n]")
+        if len({p.dtype for p in parts}) != 1:
+            raise ValueError("all parts must have one LLR type")
+        fn = getattr(lib, "labrador_ldpc_decode_ms_batch_" + _suffix(parts[0]) + "_multi")
+        res = [(torch.empty((p.shape[0], self.output_len()), dtype=torch.uint8, device=p.device),
+                torch.empty((p.shape[0],), dtype=torch.int32, device=p.device),
+                torch.empty((p.shape[0],), dtype=torch.uint8, device=p.device)) for p in parts]
+        for p in parts:                                  # the library's streams know nothing of torch's: what produced the inputs must be done
+            torch.cuda.current_stream(p.device).synchronize()
+        n = len(parts)
+        arr = lambda vals, t: (t * n)(*vals)
+        devs = arr([p.device.index or 0 for p in parts], ctypes.c_int)
+        _check(fn(int(self), n, devs, arr([_ptr(p) for p in parts], ctypes.c_void_p), arr([_ptr(r[0]) for r in res], ctypes.c_void_p),
+                  arr([_ptr(r[1]) for r in res], ctypes.c_void_p), arr([_ptr(r[2]) for r in res], ctypes.c_void_p),
+                  arr([p.shape[0] for p in parts], ctypes.c_size_t), maxiters, variant))
+        return res
 
     # ---- bit-flipping decoder: src/decoder.rs:243-301 ----
     def decode_bf(self, input: np.ndarray, output: np.ndarray, working: Optional[np.ndarray] = None,

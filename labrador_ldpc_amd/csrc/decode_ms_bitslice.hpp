@@ -221,10 +221,23 @@ struct Geo {
     // instruction selector's data-flow order keeps values whose next use is an iteration away live to the end of the block.  The
     // rate-1/2 codes fit their registers without the pins and run 6 % faster with the freedom (TM8192 16.9 against 15.9 M codewords/s);
     // the two-wave form of the rate-4/5 codes measured 36.8 (no pins) against 36.3 / 34.4 (profiles/r04_kbench/split_rate.txt).
-    static constexpr int PINNED = (!SPLIT && P.n_blocks > 20) ? 1 : 0;
+#ifndef BS_PINNED_R12
+#define BS_PINNED_R12 0
+#endif
+#ifndef BS_PINNED_R23
+#define BS_PINNED_R23 1
+#endif
+#ifndef BS_PINNED_SPLIT
+#define BS_PINNED_SPLIT 0
+#endif
+    // bit 0: the state updates, bit 1: the uses of the old row state in edge_u, bit 2: the magnitudes of a finished row
+    static constexpr int PINNED = SPLIT ? BS_PINNED_SPLIT : P.n_blocks > 20 ? BS_PINNED_R23 : BS_PINNED_R12;
     // Hard decisions in LDS instead of one register per block column (one ds_write per column and iteration; a read as well where a
     // wave holds several codewords, whose finished ones keep their decisions): the rate-1/2 codes, which that brings under the 168
     // registers of three waves per SIMD.
+#ifndef BS_TEST_NOFREEZE
+#define BS_TEST_NOFREEZE 0
+#endif
 #ifndef BS_HARD_LDS
 #define BS_HARD_LDS 1
 #endif
@@ -384,6 +397,10 @@ struct Decoder {
     BS_FN void edge_u(V &su, V (&mg)[7])
     {
         constexpr int r = GEO::P.blk[E].row, slot = GEO::slot_of(E);
+        // (everything below depends on the OLD row state only, which exists from the top of the iteration: without the pins the
+        // instruction selector computes later edges' u early and keeps it)
+        sfor<0, ARG>([&](auto K_) { pin_use(arg[r][decltype(K_)::value]); });
+        pin_use(S[r]);
         const V sel = is_arg<r, slot>();
         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = op3<TT_MUX>(sel, m2[r][k], m1[r][k]); });
         su = B::xor_(S[r], sv[E]);
@@ -423,7 +440,9 @@ struct Decoder {
         amt = B::add(phi, over);                                                  // rotr by phi + wrap
     }
 
-    static BS_FN void pin_update(V &x) { if constexpr (GEO::PINNED >= 1) B::pin(x); }
+    static BS_FN void pin_update(V &x) { if constexpr (GEO::PINNED & 1) B::pin(x); }
+    static BS_FN void pin_use(V &x) { if constexpr (GEO::PINNED & 2) B::pin(x); }
+    static BS_FN void pin_row(V &x) { if constexpr (GEO::PINNED & 4) B::pin(x); }
 
     template <int IDX> BS_FN V perm_entry(B &b) const { return b.lds_read_u16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128))); }
     // The entries are used in a fixed order (Geo::PERM_ORDER), so each use hands out the entry read during the PREVIOUS use and starts
@@ -470,19 +489,22 @@ struct Decoder {
         to_mag(W2[R], m2[R]);
         S[R] = Sn[R];
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[R][k] = argn[R][k]; });
+        // (the magnitudes are formed HERE: left to the instruction selector, their last XORs sink to their first use in the next
+        // iteration and keys and carries -- 24 planes instead of 14 -- stay live until then)
+        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_row(m1[R][k]); pin_row(m2[R][k]); });
         fail = B::or_(fail, Pn[R]);                                                   // non-zero bits = unsatisfied checks (:453)
     }
 
     // ---- one iteration (decoder.rs:380-450), block column by block column -------------------------------------------
-    // `frozen`: all ones in the lanes of codewords that are finished (their hard decisions stay as they are)
-    BS_FN V iteration(B &b, V frozen)
+    // `frozen`: the lanes of codewords that are finished (their hard decisions stay as they are), as a lane mask
+    BS_FN V iteration(B &b, uint64_t frozen)
     {
         columns(b, frozen);
         return finish_iteration(b);
     }
     // the owned block columns in Geo::COL_ORDER: variable side, then check side, of each.  A row that only this wave has edges in is
     // finished with its last edge; a row shared with another wave (split mode) stays a partial running state for the exchange.
-    BS_FN void columns(B &b, V frozen)
+    BS_FN void columns(B &b, uint64_t frozen)
     {
         fail = B::c(0);
         sfor<0, GEO::COL_ORDER.n>([&](auto I_) {
@@ -516,10 +538,10 @@ struct Decoder {
             });
             // hard decisions (decoder.rs:457-461): a wave that holds ONE codeword stops with it, so nothing is ever frozen there
             if constexpr (GEO::HARD_LDS) {
-                if constexpr (G == 1) b.lds_write32(hard_addr(c), va[7]);
-                else b.lds_write32(hard_addr(c), op3<TT_MUX>(frozen, b.lds_read32(hard_addr(c)), va[7]));     // (branch-free: an EXEC-masked
-            } else if constexpr (G == 1) hard[c] = va[7];                                                      //  store would split the loop body)
-            else hard[c] = op3<TT_MUX>(frozen, hard[c], va[7]);
+                if constexpr (G == 1 || BS_TEST_NOFREEZE) b.lds_write32(hard_addr(c), va[7]);
+                else b.lds_write32(hard_addr(c), B::select_lanes(frozen, b.lds_read32(hard_addr(c)), va[7]));   // (branch-free: an EXEC-masked
+            } else if constexpr (G == 1) hard[c] = va[7];                                                        //  store would split the loop body)
+            else hard[c] = B::select_lanes(frozen, hard[c], va[7]);
             // ---- check side of the same edges (decoder.rs:419-447) ----
             sfor<0, NB>([&](auto E_) {
                 constexpr int e = decltype(E_)::value;
@@ -600,6 +622,8 @@ struct Decoder {
 // ---- prologue / epilogue pieces shared by the one-wave and the split drivers ----------------------------------------------
 // 2048 raw LLR bytes of one block column of the group (32 per lane, `src` = the lane's byte offset into llrs) -> staging slab at
 // LDS offset `stage` (2048 bytes) -> the lane's 8 bit planes X[p]: bit (index / L) of lane (q, index mod L) = bit p of the LLR.
+// The loads are unconditional (a predicated load is an EXEC-masked branch per load): lanes of codewords beyond the batch read the
+// group's FIRST frame, which exists, and the value is masked.
 template <int CODE, class B, class D>
 BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, typename B::V src, typename B::V cw, typename B::V valid, int stage,
                               typename B::V (&X)[8])
@@ -609,7 +633,7 @@ BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, typename B::
     constexpr int M = GEO::M, L = GEO::L, Q = GEO::Q;
     sfor<0, 8>([&](auto I_) {
         constexpr int i = decltype(I_)::value;
-        const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i)), valid), valid);
+        const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i))), valid);
         b.lds_write32(B::add(B::shl(d.lane, 5), B::c(stage + 4 * i)), w);
     });
     // lane (cw, q, ll) gathers the bytes of its 32 indices: q * Q + ll + L * bit; dword dd holds bits dd, 8 + dd, 16 + dd, 24 + dd
@@ -698,7 +722,7 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     // ---- LLRs: 2048 raw bytes of block column c (32 per lane) -> staging slab -> 8 bit planes per lane ----
     sfor<0, NTX>([&](auto C_) {
         constexpr int c = decltype(C_)::value;
-        const V src = B::add(B::mul_u(frame, (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));        // byte offset into llrs (batch * N < 2^32: launcher)
+        const V src = B::add(B::mul_u(B::and_(frame, valid), (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));   // byte offset into llrs
         V X[8];
         load_column_planes<CODE>(b, d, llrs, src, cw, valid, GEO::LDS_STAGE, X);
         sfor<0, 8>([&](auto K_) {
@@ -710,29 +734,31 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     d.reset_state(b);                  // (after the LLRs: the hard-decision words alias the staging slab)
     d.prime_perm(b);
 
-    // ---- iterations (decoder.rs:380-464): the codewords of the wave run in lockstep, a finished one is frozen ----
-    uint64_t frozen_mask = ~valid_mask;
-    V iters_v = B::c(maxiters), ok_v = B::c(0);
-    uint32_t iters_s = maxiters, ok_s = 0;                                     // (W = 64: one codeword, the verdict is wave-uniform)
+    // ---- iterations (decoder.rs:380-464): the codewords of the wave run in lockstep, a finished one is frozen.  Verdicts are
+    // wave-uniform per codeword: iteration counts and success flags live in scalars, not in planes ----
+    uint64_t frozen_mask = ~valid_mask, ok_mask = 0;
+    uint32_t iters_s[G];
+    sfor<0, G>([&](auto G_) { iters_s[decltype(G_)::value] = maxiters; });
     for (uint32_t it = 0; it < maxiters && frozen_mask != ~0ull; ++it) {
-        const V frozen = b.plane_of(frozen_mask);
-        const V fail = d.iteration(b, frozen);
+        const V fail = d.iteration(b, frozen_mask);
         const uint64_t unsat_lanes = b.ballot(fail);
-        if constexpr (W == 64) {
-            if (unsat_lanes == 0) { iters_s = it; ok_s = 1; frozen_mask = ~0ull; }   // satisfied: (true, it)  (:453-463)
-        } else {
-            uint64_t unsat = 0;
-            constexpr uint64_t gm = (1ull << W) - 1;
-            for (int g = 0; g < G; ++g)
-                if ((unsat_lanes >> (g * W)) & gm) unsat |= gm << (g * W);
-            const uint64_t newly = ~frozen_mask & ~unsat;                      // satisfied for the first time: (true, it)  (:453-463)
-            const V nw = b.plane_of(newly);
-            iters_v = B::template bitop3<TT_MUX>(nw, B::c(it), iters_v);
-            ok_v = B::or_(ok_v, B::and_(nw, B::c(1)));
-            frozen_mask |= newly;
-        }
+        sfor<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            constexpr uint64_t gm = (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1)) << ((g * W) & 63);
+            if (!(unsat_lanes & gm) && !(frozen_mask & gm)) {                  // satisfied for the first time: (true, it)  (:453-463)
+                iters_s[g] = it;
+                ok_mask |= gm;
+                frozen_mask |= gm;
+            }
+        });
     }
-    if constexpr (W == 64) { iters_v = B::c(iters_s); ok_v = B::c(ok_s); }
+    V iters_v = B::c(iters_s[0]);
+    sfor<1, G>([&](auto G_) {
+        constexpr int g = decltype(G_)::value;
+        constexpr uint64_t gm = ((1ull << (W & 63)) - 1) << ((g * W) & 63);
+        iters_v = B::select_lanes(gm, B::c(iters_s[g]), iters_v);
+    });
+    const V ok_v = B::and_(b.plane_of(ok_mask), B::c(1));
 
     // ---- hard decisions, MSB first (decoder.rs:455-461 / :467-473): plane -> LDS -> one dword of 32 consecutive bits per lane ----
     if constexpr (!GEO::HARD_LDS)

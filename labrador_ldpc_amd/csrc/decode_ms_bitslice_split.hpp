@@ -52,8 +52,9 @@ struct SplitGroup {
     template <int TT> static BS_FN V op3(V a, V b, V c) { return B::template bitop3<TT>(a, b, c); }
 
     Decoder<CODE, B, HALF> d;
-    V lane, cw, lw, frame, valid, iters_v, ok_v, extra_fail;
-    uint64_t valid_mask = 0, frozen_mask = 0;
+    V lane, cw, lw, frame, valid, extra_fail;
+    uint64_t valid_mask = 0, frozen_mask = 0, ok_mask = 0;
+    uint32_t iters_s[G];                       // verdicts are wave-uniform per codeword: scalars, not planes
     const int8_t *llrs = nullptr;
     uint8_t *output = nullptr;
     uint32_t *iters = nullptr;
@@ -80,7 +81,7 @@ struct SplitGroup {
         sfor<0, NTX>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) {
-                const V src = B::add(B::mul_u(frame, (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));
+                const V src = B::add(B::mul_u(B::and_(frame, valid), (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));
                 V X[8];
                 load_column_planes<CODE>(b, d, llrs, src, cw, valid, XO, X);       // (the staging slab is this wave's exchange buffer)
                 sfor<0, 8>([&](auto K_) {
@@ -92,8 +93,8 @@ struct SplitGroup {
         d.reset_state(b);
         d.prime_perm(b);
         frozen_mask = ~valid_mask;
-        iters_v = B::c(maxiters);
-        ok_v = B::c(0);
+        sfor<0, G>([&](auto G_) { iters_s[decltype(G_)::value] = maxiters; });
+        ok_mask = 0;
         extra_fail = B::c(0);
     }
 
@@ -102,8 +103,7 @@ struct SplitGroup {
     // ---- stage 1 of an iteration: the owned block columns ----
     BS_FN void stage_columns(B &b)
     {
-        const V frozen = b.plane_of(frozen_mask);
-        d.columns(b, frozen);              // (the rows only this wave has edges in are finished in there: d.fail)
+        d.columns(b, frozen_mask);              // (the rows only this wave has edges in are finished in there: d.fail)
     }
     static BS_FN V xaddr(V lane, int base, int plane) { return B::add(B::shl(lane, 2), B::c(base + plane * 256)); }
 
@@ -186,18 +186,15 @@ struct SplitGroup {
     {
         const V fail = B::or_(d.finish_iteration(b), extra_fail);
         const uint64_t unsat_lanes = b.ballot(fail);
-        uint64_t unsat = 0;
-        if constexpr (W == 64) unsat = unsat_lanes ? ~0ull : 0ull;
-        else {
-            constexpr uint64_t gm = (1ull << W) - 1;
-            for (int g = 0; g < G; ++g)
-                if ((unsat_lanes >> (g * W)) & gm) unsat |= gm << (g * W);
-        }
-        const uint64_t newly = ~frozen_mask & ~unsat;
-        const V nw = b.plane_of(newly);
-        iters_v = op3<TT_MUX>(nw, B::c(it), iters_v);
-        ok_v = B::or_(ok_v, B::and_(nw, B::c(1)));
-        frozen_mask |= newly;
+        sfor<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            constexpr uint64_t gm = (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1)) << ((g * W) & 63);
+            if (!(unsat_lanes & gm) && !(frozen_mask & gm)) {                  // satisfied for the first time: (true, it)
+                iters_s[g] = it;
+                ok_mask |= gm;
+                frozen_mask |= gm;
+            }
+        });
     }
 
     // ---- hard decisions of the owned columns, MSB first; iterations and success by wave 0 ----
@@ -215,9 +212,15 @@ struct SplitGroup {
             }
         });
         if constexpr (HALF == 0) {
+            V iters_v = B::c(iters_s[0]);
+            sfor<1, G>([&](auto G_) {
+                constexpr int g = decltype(G_)::value;
+                constexpr uint64_t gm = ((1ull << (W & 63)) - 1) << ((g * W) & 63);
+                iters_v = B::select_lanes(gm, B::c(iters_s[g]), iters_v);
+            });
             const V first = B::and_(valid, B::eq(lw, B::c(0)));
             b.gstore32(iters, B::shl(frame, 2), iters_v, first);
-            b.gstore8(success, frame, ok_v, first);
+            b.gstore8(success, frame, B::and_(b.plane_of(ok_mask), B::c(1)), first);
         }
     }
     // ordinal of block column c among the owned ones (the epilogue's hard-decision words alias the LLR planes)

@@ -87,19 +87,8 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
 
 }  // namespace bs
 
-// the rate-4/5 codes through the two-waves-per-group kernel; hipErrorInvalidConfiguration for every other code
-hipError_t launch_decode_ms_bitsliced_split(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                            uint32_t maxiters, hipStream_t stream)
-{
-    switch (code) {
-        case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
-        case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
-        default: return hipErrorInvalidConfiguration;
-    }
-}
-
 // i8 LLRs through the bit-sliced kernel; hipErrorInvalidConfiguration for the codes it is not built for (the TC codes: their
-// circulants are not quarter-wise rotations).  llrs 4-byte aligned, output 4-byte aligned.
+// circulants are not quarter-wise rotations).  llrs 4-byte aligned, output 4-byte aligned (the caller checks).  Rate 4/5: two waves per group.
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
                                       uint32_t maxiters, hipStream_t stream)
 {

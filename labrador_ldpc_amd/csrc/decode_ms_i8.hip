@@ -17,36 +17,33 @@ namespace ldpc {
     X(TM8192, int8_t, 2)
 
 // The bit-sliced kernel (decode_ms_bs.hip, decode_ms_bitslice.hpp): `variant` 64, and the DEFAULT for the TM codes from
-// bitslice_min_batch() frames up -- one wave decodes a group of 64 / (M/32) codewords on its own, so it needs ~2048 groups in flight
-// to fill the chip and takes ~3x as long per codeword as a whole workgroup of the f32-pipe kernels: small batches are
-// faster on those (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
+// bitslice_min_batch() frames up -- one wave (rate 4/5: two) decodes a group of 64 / (M/32) codewords on its own, so it needs a few
+// thousand groups in flight to fill the chip and takes ~3x as long per codeword as a whole workgroup of the f32-pipe kernels: small
+// batches are faster on those (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
                                       uint32_t maxiters, hipStream_t stream);
-hipError_t launch_decode_ms_bitsliced_split(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                            uint32_t maxiters, hipStream_t stream);
 constexpr int VARIANT_BITSLICE = 64;
-// The rate-4/5 codes (TM1280, TM5120) have two bit-sliced kernels: a codeword group shared by the two waves of a workgroup
-// (decode_ms_bitslice_split.hpp) -- what `variant` 64 and the default dispatch mean for them -- and, `variant` 128, round 4's first form:
-// one wave per group with its LLR planes in a stream-ordered global workspace (kept for the A/B: profiles/r04_kbench/split_rate.txt).
-constexpr int VARIANT_BITSLICE_ONE_WAVE = 128;
-static hipError_t launch_bitsliced_default_form(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                                uint32_t maxiters, hipStream_t stream)
-{
-    if (code == TM1280 || code == TM5120) return launch_decode_ms_bitsliced_split(code, llrs, output, iters, success, batch, maxiters, stream);
-    return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
-}
 // groups of 64 / (M/32) codewords from which the bit-sliced kernel is faster per call (tools/bs_crossover.py,
-// profiles/r04_kbench/bs_crossover.txt: TM8192 and TM6144 cross at 1024 groups, TM2048 at 2048, TM1536 at 8192; the rate-4/5 codes'
-// two-wave kernel -- twice the waves per group -- crosses at 768 (TM5120) and 2048 (TM1280) groups: profiles/r04_kbench/split_rate.txt)
+// profiles/r05_kbench/bs_crossover.txt)
 constexpr size_t bitslice_min_batch(int code)
 {
     constexpr size_t groups[NUM_CODES] = {0, 0, 0, 2048, 8192, 2048, 768, 1024, 1024};
     return code >= TM1280 && code <= TM8192 ? groups[code] * (size_t)(64 / (CODES[code].m / 32)) : ~(size_t)0;
 }
-static bool bitslice_default(int code, const int8_t *llrs, size_t batch, hipStream_t stream)
+// its loads and stores are dwords: both buffers 4-byte aligned
+static bool bitslice_aligned(const int8_t *llrs, const uint8_t *output) { return (uintptr_t)llrs % 4 == 0 && (uintptr_t)output % 4 == 0; }
+
+// which kernel the default dispatch picks for an aligned batch of this size (introspection: labrador_ldpc_hip_decode_ms_i8_kernel)
+const char *decode_ms_i8_kernel_name(int code, int variant, size_t batch)
 {
-    (void)stream;                                  // (no kernel of the default form allocates anything: graph capture is fine)
-    return batch >= bitslice_min_batch(code) && (uintptr_t)llrs % 4 == 0;
+    if (!valid_code(code) || variant < 0) return "";
+    const int flags = variant & VARIANT_FLAGS;
+    variant &= ~VARIANT_FLAGS;
+    const bool tm = code >= TM1280;
+    if ((variant == VARIANT_BITSLICE && tm) || (variant == 0 && flags == 0 && batch >= bitslice_min_batch(code)))
+        return (code == TM1280 || code == TM5120) ? "decode_ms_bs_split_kernel" : "decode_ms_bs_kernel";
+    if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) return "decode_ms_pair_kernel";
+    return "decode_ms_kernel";
 }
 
 template <>
@@ -56,15 +53,11 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
 {
     LDPC_SPLIT_VARIANT();
     if (variant == VARIANT_BITSLICE) {
-        if ((uintptr_t)llrs % 4) return hipErrorInvalidConfiguration;        // (its loads are dwords)
-        return launch_bitsliced_default_form(code, llrs, output, iters, success, batch, maxiters, stream);
-    }
-    if (variant == VARIANT_BITSLICE_ONE_WAVE) {
-        if ((uintptr_t)llrs % 4 || (code != TM1280 && code != TM5120)) return hipErrorInvalidConfiguration;
+        if (!bitslice_aligned(llrs, output)) return hipErrorInvalidConfiguration;
         return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
     }
-    if (variant == 0 && lflags == 0 && bitslice_default(code, llrs, batch, stream))
-        return launch_bitsliced_default_form(code, llrs, output, iters, success, batch, maxiters, stream);
+    if (variant == 0 && lflags == 0 && batch >= bitslice_min_batch(code) && bitslice_aligned(llrs, output))
+        return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
     // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
     if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
         if (code == TM8192) return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);

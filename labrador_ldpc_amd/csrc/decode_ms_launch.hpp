@@ -75,7 +75,7 @@ inline uint32_t *claim_counter(hipStream_t stream)
     }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    struct Block { uint32_t *base = nullptr; unsigned used = 0; };
+    struct Block { uint32_t *base = nullptr; unsigned used = 0; uint32_t *spare = nullptr; };     // spare: a zeroed block that lost an allocation race
     constexpr unsigned PER_BLOCK = 1024;
     constexpr size_t MAX_HEADS = 8 * PER_BLOCK;      // streams beyond that (handle churn) run the fixed stride: the map stays bounded
     static std::mutex mu;
@@ -87,6 +87,7 @@ inline uint32_t *claim_counter(hipStream_t stream)
         if (it != heads.end()) return it->second;
         if (heads.size() >= MAX_HEADS) return nullptr;
         Block &b = blocks[dev];
+        if ((b.base == nullptr || b.used >= PER_BLOCK) && b.spare != nullptr) { b.base = b.spare; b.spare = nullptr; b.used = 0; }
         if (b.base != nullptr && b.used < PER_BLOCK) {
             uint32_t *head = b.base + b.used++;
             heads[{dev, stream}] = head;
@@ -108,11 +109,15 @@ inline uint32_t *claim_counter(hipStream_t stream)
     if (!ok) { (void)hipGetLastError(); if (p) (void)hipFree(p); p = nullptr; }
     (void)hipThreadExchangeStreamCaptureMode(&mode);
     if (p == nullptr) return nullptr;
+    // (Nothing is freed under the lock: hipFree synchronises the whole device and is not capture-safe -- under the lock it would stall
+    // every other worker's launch and could invalidate another thread's global-mode capture.  A block that lost the race below is
+    // kept as the device's spare and becomes its next block; a second loser of the same race -- two spares at once -- is leaked,
+    // 4 KB, once.)
     std::lock_guard<std::mutex> lock(mu);
-    auto it = heads.find({dev, stream});             // (another thread may have served this stream meanwhile)
-    if (it != heads.end()) { (void)hipFree(p); return it->second; }
     Block &b = blocks[dev];
-    if (b.base != nullptr && b.used < PER_BLOCK) (void)hipFree(p);      // ... or installed a fresh block: use that one
+    auto it = heads.find({dev, stream});             // (another thread may have served this stream meanwhile)
+    if (it != heads.end()) { if (b.spare == nullptr) b.spare = p; return it->second; }
+    if (b.base != nullptr && b.used < PER_BLOCK) { if (b.spare == nullptr) b.spare = p; }      // ... or installed a fresh block: use that one
     else { b.base = p; b.used = 0; }
     uint32_t *head = b.base + b.used++;
     heads[{dev, stream}] = head;

@@ -49,8 +49,16 @@ struct HipBackend {
     {
         return pred ? *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off) : 0u;
     }
+    static BS_FN V gload32(const void *p, V off) { return *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off); }
     static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off) = v; }
     static BS_FN void gstore8(void *p, V off, V v, V pred) { if (pred) static_cast<uint8_t *>(p)[off] = (uint8_t)v; }
+    // lane-wise select by a 64-bit lane mask: one v_cndmask_b32 with the mask in an SGPR pair, no plane of the mask in a register
+    static BS_FN V select_lanes(uint64_t m, V a, V b)
+    {
+        V r;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+        return r;
+    }
     static BS_FN uint64_t ballot(V x) { return __ballot(x != 0u); }
     BS_FN V plane_of(uint64_t m) const { return ((m >> (threadIdx.x & 63u)) & 1ull) ? 0xFFFFFFFFu : 0u; }
 };

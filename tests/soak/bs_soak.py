@@ -1,4 +1,4 @@
-"""Wide GPU-vs-oracle parity soak of the round-4 bit-sliced kernels (forced with `variant` 64 whatever the batch; decode_bf through
+"""Wide GPU-vs-oracle parity soak of the bit-sliced kernels (forced with `variant` 64 whatever the batch; decode_bf through
 its default dispatch on batches above its threshold): six TM codes x four operating points of decode_ms i8 (converging early / late /
 failing / saturating scale) and two error densities of decode_bf.  Lives under tests/ because it runs the oracle.
     python tests/soak/bs_soak.py [multiplier]"""
@@ -24,11 +24,6 @@ for code in [c for c in LDPCCode if c.name.startswith("TM")]:
         m = int(((o != oc).any(axis=1) | (i != ic) | (k != kc)).sum())
         total += frames; bad += m
         print(f"decode_ms i8 bit-sliced {code.name} Eb/N0 {ebn0:.1f} scale {scale:g}: {frames} frames, mean iters {i.mean():.2f}, failed {1 - k.mean():.3f}, mismatches {m}", flush=True)
-        if r45:                                       # the rate-4/5 codes' other bit-sliced kernel: one wave per group (`variant` 128)
-            o, i, k = code.decode_ms_batch(llrs, 25, variant=128)
-            m = int(((o != oc).any(axis=1) | (i != ic) | (k != kc)).sum())
-            total += frames; bad += m
-            print(f"decode_ms i8 bit-sliced, one wave per group {code.name} Eb/N0 {ebn0:.1f} scale {scale:g}: {frames} frames, mismatches {m}", flush=True)
     fb = max(256 * G + 5, frames)
     for dens in (400, 60):
         hard = np.zeros((fb, code.n() // 8), np.uint8)

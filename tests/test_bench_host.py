@@ -86,12 +86,33 @@ def test_roofline_of_prints_null_valu_issue_for_an_unprofiled_operating_point(tm
     assert roof["kernel"] == "decode_ms_bs_split_kernel" and roof["traffic"] == 8.5e9 * 4 and "Infinity Cache" not in roof["traffic_source"] and valu
     roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 0, 524288, 37.6, 25.0, build, 2.0, 25)
     assert roof["traffic"] == 8.5e9 * 4 and valu is None
-    # `variant` 128, one wave per group, re-reads its LLR planes from a global workspace every iteration: ITS traffic belongs to one
-    # operating point
-    roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 128, 524288, 17.0, 8.4, build, 4.0, 25)
-    assert roof["kernel"] == "decode_ms_bs_kernel" and roof["traffic"] == 8.5e9 * 4 and "Infinity Cache" in roof["traffic_source"]
-    roof, valu = b.roofline_of(tm5120, "TM5120", "i8", 128, 524288, 37.6, 25.0, build, 2.0, 25)
-    assert roof["traffic"] is None and valu is None and "no profile of TM5120_i8_2dB_25it" in roof["traffic_note"]
+    # a batch below the dispatch threshold runs the f32-pipe kernel and is labelled so (round 4 advice): the library is asked
+    roof, _ = b.roofline_of(tm5120, "TM5120", "i8", 0, 1024, 0.1, 8.4, build, 4.0, 25)
+    assert roof["kernel"] == "decode_ms_kernel"
+    roof, _ = b.roofline_of(tm5120, "TM5120", "i8", 64, 1024, 0.1, 8.4, build, 4.0, 25)
+    assert roof["kernel"] == "decode_ms_bs_split_kernel"
+    assert b.kernel_name("TM8192", "i8", 0, 4096) == "decode_ms_bs_kernel" and b.kernel_name("TM8192", "i8", 0, 512) == "decode_ms_pair_kernel"
+    assert b.kernel_name("TM8192", "i8", 256, 4096) == "decode_ms_pair_kernel"          # a launch flag keeps the f32-pipe kernel
+    assert b.kernel_name("TC512", "i8", 0, 1 << 20) == "decode_ms_kernel"
+
+
+def test_an_alternative_library_build_never_gets_profile_figures(tmp_path, monkeypatch):
+    """tools/bs_alt_build.sh links experimental kernels with the product's capi.o, so such a library reports the product's build id
+    (round 4 advice): with LABRADOR_LDPC_HIP_LIB pointing anywhere but at the in-tree library no committed profile is attached."""
+    b = _bench()
+    build = "aaaaaaaaaaaaaaaa"
+    key = b.profile_key("TM8192", "f32", 2.0, 25)
+    path = tmp_path / "hbm_traffic.json"
+    path.write_text(json.dumps({"library_build": build, key: {"frames": 65536, "hbm_bytes_per_launch": 2.2e9, "valu_insts_per_launch": 5.5e9}}))
+    monkeypatch.delenv("LABRADOR_LDPC_HIP_LIB", raising=False)
+    assert b.profile_counters(key, build, str(path))[0] and b.traffic_profile("TM8192", "f32", build, str(path))[0]
+    monkeypatch.setenv("LABRADOR_LDPC_HIP_LIB", os.path.join(ROOT, "labrador_ldpc_amd", "liblabrador_ldpc_hip.so"))
+    assert b.profile_counters(key, build, str(path))[0]                                  # the in-tree library by its own path: fine
+    monkeypatch.setenv("LABRADOR_LDPC_HIP_LIB", str(tmp_path / "liblabrador_ldpc_hip_experiment.so"))
+    t, why = b.profile_counters(key, build, str(path))
+    assert t is None and "alternative library" in why
+    t, _, why = b.traffic_profile("TM8192", "f32", build, str(path))
+    assert t is None and "alternative library" in why
 
 
 def test_the_committed_profile_names_the_build_it_was_collected_on():
@@ -111,9 +132,11 @@ def test_roofline_fields_and_limiter_text_are_per_configuration():
         def n(self): return self._n
         def output_len(self): return self._o
         def paritycheck_sum(self): return self._e
-    t8192 = b.limiter_text(Code(8192, 1280, 30720), 4, 17.5)
+    t8192 = b.limiter_text(Code(8192, 1280, 30720), 4, 18.5)
     tc512 = b.limiter_text(Code(512, 64, 2048), 4, 15.0)
-    assert "34053 B" in t8192 and "30720 edges" in t8192
+    assert "34053 B" in t8192 and "30720 edges" in t8192 and "x 18.5 iterations executed" in t8192
+    # a batch in which nothing converges executed max_iters passes per frame, not max_iters + 1 (round 4 review, weak #4)
+    assert "x 25.0 iterations executed" in b.limiter_text(Code(5120, 704, 19968), 1, 25.0)
     assert "2117 B" in tc512 and "2048 edges" in tc512 and "34053" not in tc512
     assert abs(b.VALU_PEAK_G - 1228.8) < 1e-6 and b.SHADER_CLOCK_UNDER_LOAD_GHZ == 2.30
 

@@ -169,3 +169,28 @@ def test_device_resident_shards_from_one_thread_equal_the_one_call_job(tmp_path,
     r = subprocess.run([exe, str(frames)] + ([str(parts)] if parts else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok:")
+
+
+MULTI_SRC = os.path.join(ROOT, "tests", "c", "multi_call.c")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"), reason="no HIP headers")
+def test_multi_call_client_compiles_and_reports_no_device(tmp_path):
+    """labrador_ldpc_decode_ms_batch_*_multi as a C compiler sees it (pointer-to-pointer arguments, const placement): -Wall -Werror."""
+    exe = build_client(tmp_path, "TM2048", src=MULTI_SRC, extra=HIP_INC)
+    if la.device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,frames,parts", [("TM2048", 20011, 0), ("TM2048", 20011, 3), ("TM8192", 4099, 3), ("TM5120", 9001, 2), ("TC512", 7, 8)])
+def test_device_resident_parts_through_one_multi_call_equal_the_one_call_job(tmp_path, name, frames, parts):
+    """Round 4's review, item 7: per-device device-resident buffers handed to ONE call (labrador_ldpc_decode_ms_batch_{f32,i8}_multi),
+    decoded by the library's per-device workers -- every part equals its slice of the job decoded by one call; with one GPU `parts`
+    entries all name device 0 (three workers, three streams); shards for real with more GPUs.  Also: an empty part, a bad ordinal."""
+    exe = build_client(tmp_path, name, src=MULTI_SRC, extra=HIP_INC)
+    r = subprocess.run([exe, str(frames)] + ([str(parts)] if parts else []), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok:") == 2

@@ -108,10 +108,15 @@ def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
         assert len(perm) >= 100, name
         loop = body[perm[0]:perm[-1]]
         n = sum(1 for t in loop if t.startswith("scratch_"))
-        assert n == 0, f"{name}: {n} scratch instructions inside the iteration"
+        # The rate-1/2 kernels (TM2048 = code 5, TM8192 = 8) are compiled for THREE waves per SIMD (168 registers), which the allocator
+        # meets with a handful of spilled values whose next use is most of an iteration away (round 5, measured: 20.6 M codewords/s
+        # with ~10 spills against 19.7 with none under scheduling pins and 17.6 at two waves per SIMD, profiles/r05_kbench/bs_occupancy.txt);
+        # a regression that spills in earnest (68 values cost TM2048 half its rate) must still fail here.
+        r12 = "ILi5E" in name or "ILi8E" in name
+        assert n <= (24 if r12 else 0), f"{name}: {n} scratch instructions inside the iteration"
         assert sum(1 for t in loop if t.startswith("v_bitop3_b32")) > 0.6 * len(loop) - 200      # ... which is Boolean arithmetic
         seen += 1
-    assert seen == 6
+    assert seen == 4                                       # TM1536, TM2048, TM6144, TM8192 (the rate-4/5 codes: the split kernel below)
     # the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp): no scratch memory ANYWHERE (its state fits
     # the registers: nothing is spilled, prologue and epilogue included), no global access inside the iterations (the LLR planes live in
     # LDS), and exactly two workgroup barriers per iteration and wave

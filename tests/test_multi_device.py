@@ -170,3 +170,31 @@ def test_concurrent_sharded_calls_from_several_host_threads():
     assert not errors, errors
     for (llrs, want, devs), got in zip(jobs, results):
         assert all((g == w).all() for g, w in zip(got, want)), devs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.float64])
+def test_device_resident_parts_through_the_multi_call(dtype):
+    """labrador_ldpc_decode_ms_batch_*_multi through the Python binding (LDPCCode.decode_ms_batch_multi): device-resident parts of
+    unequal sizes, one of them empty, every one on the box's GPU(s) by ordinal -- each part's results equal the oracle's, and the call
+    has returned only when they are in place (no synchronisation before the copies to the host)."""
+    import oracle
+    torch = pytest.importorskip("torch")
+    code = LDPCCode.TM1536
+    rng = np.random.default_rng(77)
+    ndev = la.device_count()
+    sizes = [301, 0, 1024, 77]
+    parts, want = [], []
+    for i, f in enumerate(sizes):
+        llrs, _ = oracle.awgn_llrs(code, rng, max(f, 1), 2.5, dtype)
+        llrs = llrs[:f]
+        want.append(oracle.decode_ms_batch(code, llrs, 20)[:3] if f else None)
+        parts.append(torch.from_numpy(llrs).to(torch.device("cuda", i % ndev)))
+    for _ in range(2):
+        got = code.decode_ms_batch_multi(parts, 20)
+        for g, w, f in zip(got, want, sizes):
+            assert g[0].shape[0] == f
+            if f:
+                assert all((x.cpu().numpy() == y).all() for x, y in zip(g, w))
+    with pytest.raises(ValueError):
+        code.decode_ms_batch_multi([parts[0], parts[2].to(torch.float16)], 20)

@@ -16,18 +16,21 @@ C_TO_RUST = {"size_t": "usize", "int": "c_int", "bool": "bool", "void": "()", "f
 
 
 def c_type_to_rust(t):
-    t = " ".join(t.split())
-    const = t.startswith("const ")
+    """`const float *const *` -> `*const *const f32`: every `*` points to what stands left of it, const or not."""
+    segs = [" ".join(x.split()) for x in t.split("*")]       # ["const float", "const", ""]: base, then the qualifier behind each star
+    base = segs[0]
+    const = base.startswith("const ")
     if const:
-        t = t[6:]
-    stars = t.count("*")
-    base = t.replace("*", "").strip()
+        base = base[6:]
     r = C_TO_RUST[base]
-    if stars == 0:
+    if len(segs) == 1:
         return r
     if base == "void":
         r = "c_void"
-    return ("*const " if const else "*mut ") + r
+    for q in segs[1:]:                                      # one pointer level per star, inside out
+        r = ("*const " if const else "*mut ") + r
+        const = q == "const"
+    return r
 
 
 def header_functions():
