@@ -80,6 +80,11 @@ inline constexpr int TT_AND3 = tt_of([](bool a, bool b, bool c) -> bool { return
 inline constexpr int TT_OVF = tt_of([](bool a7, bool s, bool sum7) -> bool { return (a7 == s) && (sum7 != a7); });
 // saturated plane 0..6: (ovf, a7, sum) -> ovf ? ~a7 : sum     (0x7F for a >= 0, 0x80 for a < 0)
 inline constexpr int TT_SAT = tt_of([](bool ovf, bool a7, bool sum) -> bool { return ovf ? !a7 : sum; });
+// The adder with its addend given INVERTED (x = ~xr, s = ~sr: subtracting what was added): the complements ride in the truth tables
+inline constexpr int TT_XNOR3 = tt_of([](bool a, bool b, bool c) -> bool { return !(a ^ b ^ c); });                                   // a ^ ~b ^ c
+inline constexpr int TT_MAJ_NB = tt_of([](bool a, bool b, bool c) -> bool { return (a && !b) || (c && (a || !b)); });                 // maj(a, ~b, c)
+inline constexpr int TT_MAJ_NBC = tt_of([](bool a, bool b, bool c) -> bool { return (a && !b) || (!c && (a || !b)); });               // maj(a, ~b, ~c)
+inline constexpr int TT_OVF_NS = tt_of([](bool a7, bool s, bool sum7) -> bool { return (a7 == !s) && (sum7 != a7); });               // overflow with sign ~s
 // borrow of a - b, one plane: (b, a, borrow in) -> maj(~a, b, borrow)
 inline constexpr int TT_BORROW = tt_of([](bool b, bool a, bool br) -> bool { return (!a && b) || (br && (!a || b)); });
 // self-correction: (nz, sv, nv7) -> the old v was non-zero and the new sign differs
@@ -244,12 +249,12 @@ struct Geo {
     static constexpr bool HARD_LDS = !SPLIT && P.n_blocks <= 20 && BS_HARD_LDS;
     static constexpr int ROW_NEW = 18 + ARG;                                   // planes of a row's running state
     // LDS of a wave: lane permutations of the exchanged blocks [NX][2 directions][64] as 16-bit entries (source lane address | rotate
-    // amount << 8; constant for the kernel's lifetime), hard-decision words [NCOLS][64] -- which double as the 2048-byte staging slab
+    // amount << 8; constant for the kernel's lifetime), hard-decision words [NCOLS][64] -- which double as the staging slab (STAGE_BYTES)
     // of the LLR transposition (prologue only) --, LLR planes [NTX][8][64].
     // Split mode: a wave's private area is [permutations | LLR planes]; the hard-decision words of the epilogue alias the LLR planes
     // (dead by then) and the staging slab is the wave's exchange buffer, which lies behind both private areas (SplitLayout).
     static constexpr int LDS_PERM = 0, LDS_PERM_END = LDS_PERM + NX * 2 * 64 * 2;
-    static constexpr int HARD_BYTES = NCOLS_OWN * 256 > 2048 ? NCOLS_OWN * 256 : 2048;
+    static constexpr int HARD_BYTES = NCOLS_OWN * 256 > 2304 ? NCOLS_OWN * 256 : 2304;             // (>= STAGE_BYTES, a multiple of 256)
     static constexpr int LDS_HARD = LDS_PERM_END, LDS_STAGE = LDS_HARD,
                          LDS_LLR = SPLIT ? LDS_PERM_END : LDS_HARD + HARD_BYTES,
                          LDS_PRIVATE = LDS_LLR + LLR_WORDS * 4,
@@ -264,24 +269,24 @@ struct Arith {
     using V = typename B::V;
     template <int TT> static BS_FN V op3(V a, V b, V c) { return B::template bitop3<TT>(a, b, c); }
 
-    // acc (+sat) / (-sat) u for two's-complement acc[8] and sign-magnitude u = (su, mg[7]), i8 saturation (decoder.rs:47-48).
-    // `negate` subtracts: the sign of u is flipped (u is never -128: |u| <= 127).
-    template <bool NEGATE>
-    static BS_FN void sat_addsub(V (&acc)[8], V su, const V (&mg)[7])
+    // acc (+sat) w, i8 saturation (decoder.rs:47-48), for two's-complement acc[8] and a sign-magnitude w = (sr, magnitude) handed over as
+    // xr[k] = magnitude[k] ^ sr (one's complement if negative; the
+    // + 1 rides on the carry-in sr).  INV: acc (-sat) w instead -- every bit of the addend inverted, which costs nothing: the truth
+    // tables absorb the complements.  So one xr serves the variable side (add u) and the check side (subtract the same u) of an edge.
+    template <bool INV>
+    static BS_FN void sat_add_x(V (&acc)[8], V sr, const V (&xr)[7])
     {
-        const V s = NEGATE ? B::not_(su) : su;                // sign of the addend
-        V x[7], sum[8];
-        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], s); });     // one's complement if negative ...
-        V c = s;                                              // ... + 1 through the carry-in
-        sfor<0, 7>([&](auto K_) {
+        V sum[8];
+        // stage 0: carry-in = the addend's sign; a ^ ~x ^ ~s = a ^ x ^ s
+        sum[0] = op3<TT_XOR3>(acc[0], xr[0], sr);
+        V c = INV ? op3<TT_MAJ_NBC>(acc[0], xr[0], sr) : op3<TT_MAJ>(acc[0], xr[0], sr);
+        sfor<1, 7>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            sum[k] = op3<TT_XOR3>(acc[k], x[k], c);
-            c = op3<TT_MAJ>(acc[k], x[k], c);
+            sum[k] = INV ? op3<TT_XNOR3>(acc[k], xr[k], c) : op3<TT_XOR3>(acc[k], xr[k], c);
+            c = INV ? op3<TT_MAJ_NB>(acc[k], xr[k], c) : op3<TT_MAJ>(acc[k], xr[k], c);
         });
-        sum[7] = op3<TT_XOR3>(acc[7], s, c);                  // the addend's bit 7 is its sign (sign extension)
-        // overflow iff both operands have the same sign and the sum's differs
-        const V ovf = op3<TT_OVF>(acc[7], s, sum[7]);
-        // saturated value: 0x7F if acc >= 0 (a7 = 0), 0x80 if acc < 0: planes 0..6 = ~a7, plane 7 = a7
+        sum[7] = INV ? op3<TT_XNOR3>(acc[7], sr, c) : op3<TT_XOR3>(acc[7], sr, c);       // the addend's bit 7 is its sign (sign extension)
+        const V ovf = INV ? op3<TT_OVF_NS>(acc[7], sr, sum[7]) : op3<TT_OVF>(acc[7], sr, sum[7]);
         const V a7 = acc[7];
         sfor<0, 7>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
@@ -521,10 +526,12 @@ struct Decoder {
             } else {
                 sfor<0, 8>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
             }
+            // (u of a LOCAL edge -- an unshifted identity block: check and variable alignment coincide -- is the same expression here
+            // and on the check side below, where the adder takes it inverted: the compiler forms it once)
             sfor<0, NB>([&](auto E_) {
                 constexpr int e = decltype(E_)::value;
                 if constexpr (GEO::P.blk[e].col == c) {
-                    V su, mg[7];
+                    V su, mg[7], x[7];
                     edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
                         const V addr = take_perm<GEO::exch_of(e) * 2 + 0>(b);
@@ -532,7 +539,8 @@ struct Decoder {
                         sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
                         su = B::rotr(b.bperm(addr, su), amt);
                     }
-                    A::template sat_addsub<false>(va, su, mg);
+                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    A::template sat_add_x<false>(va, su, x);
                     B::fence();
                 }
             });
@@ -556,9 +564,10 @@ struct Decoder {
                         sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
                     }
                     const V pbit = nv[7];                                            // hard bit of the marginal (:445-447)
-                    V su, mg[7];
+                    V su, mg[7], x[7];
                     edge_u<e>(su, mg);
-                    A::template sat_addsub<true>(nv, su, mg);                        // new_v_ai = va (-sat) u            (:421)
+                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    A::template sat_add_x<true>(nv, su, x);                          // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
                     const V drop = op3<TT_DROP>(nz[e], sv[e], nv[7]);
                     // v = drop ? 0 : nv is never formed: its sign, its key and "v != 0" follow from nv and drop directly.
@@ -620,30 +629,52 @@ struct Decoder {
 };
 
 // ---- prologue / epilogue pieces shared by the one-wave and the split drivers ----------------------------------------------
-// 2048 raw LLR bytes of one block column of the group (32 per lane, `src` = the lane's byte offset into llrs) -> staging slab at
-// LDS offset `stage` (2048 bytes) -> the lane's 8 bit planes X[p]: bit (index / L) of lane (q, index mod L) = bit p of the LLR.
-// The loads are unconditional (a predicated load is an EXEC-masked branch per load): lanes of codewords beyond the batch read the
-// group's FIRST frame, which exists, and the value is masked.
+// The 2048 raw LLR bytes of one block column of a group (M per codeword, G codewords) pass through a staging slab in LDS:
+// position p = codeword * M + index.  The slab is SKEWED -- 16 bytes of padding after every 256 -- so that the byte gather below,
+// whose lanes read at strides of Q and M, finds its 64 bytes in different banks (conflict-free for M >= 512, 2-way for TM1536, 4-way
+// for TM1280, where every lane reads a dword of its own; unskewed: 4- to 8-way, all of SQ_LDS_BANK_CONFLICT of round 4's kernels).
+constexpr int STAGE_BYTES = 2048 + 16 * 8;
+constexpr int stage_skew(int p) { return p + 16 * (p / 256); }
+
+// block column c of the group's LLRs -> the lane's 8 bit planes X[p]: bit (index / L) of lane (q, index mod L) = bit p of the LLR.
+// Global side: two 16-byte loads per lane, consecutive lanes consecutive bytes (the wave reads the column's 128-byte lines whole,
+// once).  The loads are unconditional (a predicated load is an EXEC-masked branch per load): lanes of codewords beyond the batch read
+// the group's FIRST frame, which exists, and the value is masked.
 template <int CODE, class B, class D>
-BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, typename B::V src, typename B::V cw, typename B::V valid, int stage,
-                              typename B::V (&X)[8])
+BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, int c, uint32_t group, uint32_t batch, int stage, typename B::V (&X)[8])
 {
     using GEO = Geo<CODE>;
     using V = typename B::V;
-    constexpr int M = GEO::M, L = GEO::L, Q = GEO::Q;
-    sfor<0, 8>([&](auto I_) {
-        constexpr int i = decltype(I_)::value;
-        const V w = B::and_(b.gload32(llrs, B::add(src, B::c(4 * i))), valid);
-        b.lds_write32(B::add(B::shl(d.lane, 5), B::c(stage + 4 * i)), w);
+    constexpr int M = GEO::M, N = GEO::N, L = GEO::L, Q = GEO::Q, W = GEO::W, G = GEO::G;
+    sfor<0, 2>([&](auto H_) {
+        constexpr int h = decltype(H_)::value;
+        const V p = B::add(B::shl(d.lane, 4), B::c(1024 * h));                               // slab position of the lane's 16 bytes
+        const V pcw = B::shr(p, ilog2c(M));                                                   // their codeword inside the group
+        const V ok = B::less_u(B::add(B::c(group * (uint32_t)G), pcw), B::c(batch));
+        const V src = B::add(B::mul_u(B::and_(pcw, ok), (uint32_t)N), B::add(B::c((uint32_t)c * M), B::and_(p, B::c(M - 1))));
+        V w[4];
+        b.gload128(llrs, src, w);
+        sfor<0, 4>([&](auto I_) { constexpr int i = decltype(I_)::value; w[i] = B::and_(w[i], ok); });
+        b.lds_write128(B::add(B::add(p, B::shl(B::shr(p, 8), 4)), B::c(stage)), w);          // stage_skew(p)
     });
     // lane (cw, q, ll) gathers the bytes of its 32 indices: q * Q + ll + L * bit; dword dd holds bits dd, 8 + dd, 16 + dd, 24 + dd
-    const V base = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), B::add(d.ll, B::c(stage)));
+    const V cw = B::shr(d.lane, ilog2c(W));
+    const V p0 = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), d.ll);       // position of bit 0
+    auto at = [&](int bit) {                                                                  // skewed LDS address of bit `bit`
+        if constexpr (L * 32 <= 256 && 256 % (L * 32) == 0) {
+            // the lane's 32 bytes lie inside one 256-byte run: one skew for all of them
+            return B::add(B::add(p0, B::shl(B::shr(p0, 8), 4)), B::c(stage + L * bit));
+        } else {
+            const V pp = B::add(p0, B::c(L * bit));
+            return B::add(B::add(pp, B::shl(B::shr(pp, 8), 4)), B::c(stage));
+        }
+    };
     sfor<0, 8>([&](auto D_) {
         constexpr int dd = decltype(D_)::value;
-        V x = b.lds_read_u8(B::add(base, B::c(L * dd)));
-        x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (8 + dd)))), 8));
-        x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (16 + dd)))), 16));
-        x = B::or_(x, B::shl(b.lds_read_u8(B::add(base, B::c(L * (24 + dd)))), 24));
+        V x = b.lds_read_u8(at(dd));
+        x = B::or_(x, B::shl(b.lds_read_u8(at(8 + dd)), 8));
+        x = B::or_(x, B::shl(b.lds_read_u8(at(16 + dd)), 16));
+        x = B::or_(x, B::shl(b.lds_read_u8(at(24 + dd)), 24));
         X[dd] = x;
     });
     // 8 x 8 bit-matrix transpose inside every byte lane: afterwards X[p] byte y bit dd = bit p of LLR (8 y + dd)
@@ -705,26 +736,23 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
 {
     using GEO = Geo<CODE>;
     using V = typename B::V;
-    constexpr int M = GEO::M, N = GEO::N, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS;
+    constexpr int M = GEO::M, W = GEO::W, G = GEO::G, NTX = GEO::NTX, NCOLS = GEO::NCOLS;
     Decoder<CODE, B> d;
     d.init_lane(b);
     const V lane = d.lane;
     const V cw = B::shr(lane, ilog2c(W));                                    // codeword of the lane inside the group (0 for W = 64)
-    const V lw = B::and_(lane, B::c(W - 1));                                 // lane inside the codeword
     const int8_t *llrs = llrs_all + (size_t)group * G * GEO::N;
     uint8_t *output = output_all + (size_t)group * G * GEO::OUT_LEN;
     uint32_t *iters = iters_all + (size_t)group * G;
     uint8_t *success = success_all + (size_t)group * G;
-    const V frame = cw;                                                      // frame index relative to the group's first
     const V valid = B::less_u(B::add(B::c(group * (uint32_t)G), cw), B::c(batch));      // all ones where the lane's codeword exists
     const uint64_t valid_mask = b.ballot(valid);
 
     // ---- LLRs: 2048 raw bytes of block column c (32 per lane) -> staging slab -> 8 bit planes per lane ----
     sfor<0, NTX>([&](auto C_) {
         constexpr int c = decltype(C_)::value;
-        const V src = B::add(B::mul_u(B::and_(frame, valid), (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));   // byte offset into llrs
         V X[8];
-        load_column_planes<CODE>(b, d, llrs, src, cw, valid, GEO::LDS_STAGE, X);
+        load_column_planes<CODE>(b, d, llrs, c, group, batch, GEO::LDS_STAGE, X);
         sfor<0, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);

@@ -33,7 +33,7 @@ struct SplitLayout {
     static constexpr int XEXTRA = 18 + G0::ARG;                               // W1 8, W2 8, Sn, Pn, argn ARG; then the parity of the unshared rows
     static constexpr int XPLANES = XEXTRA + 1;
     static constexpr int XBYTES = XPLANES * 256;
-    static_assert(XBYTES >= 2048, "the exchange buffer doubles as the staging slab of the LLR transposition");
+    static_assert(XBYTES >= STAGE_BYTES, "the exchange buffer doubles as the staging slab of the LLR transposition");
     static constexpr int PRIV0 = 0, PRIV1 = G0::LDS_PRIVATE, XBUF0 = PRIV1 + G1::LDS_PRIVATE, XBUF1 = XBUF0 + XBYTES, BYTES = XBUF1 + XBYTES;
     template <int H> static constexpr int priv() { return H == 0 ? PRIV0 : PRIV1; }
     template <int H> static constexpr int own_x() { return (H == 0 ? XBUF0 : XBUF1) - priv<H>(); }      // relative to the wave's private base
@@ -81,9 +81,8 @@ struct SplitGroup {
         sfor<0, NTX>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) {
-                const V src = B::add(B::mul_u(B::and_(frame, valid), (uint32_t)N), B::add(B::c((uint32_t)c * M), B::shl(lw, 5)));
                 V X[8];
-                load_column_planes<CODE>(b, d, llrs, src, cw, valid, XO, X);       // (the staging slab is this wave's exchange buffer)
+                load_column_planes<CODE>(b, d, llrs, c, group, batch, XO, X);      // (the staging slab is this wave's exchange buffer)
                 sfor<0, 8>([&](auto K_) {
                     constexpr int k = decltype(K_)::value;
                     b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)), X[k]);

@@ -50,6 +50,18 @@ struct HipBackend {
         return pred ? *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off) : 0u;
     }
     static BS_FN V gload32(const void *p, V off) { return *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off); }
+    // 16 bytes per lane at a 4-byte-aligned address (global_load_dwordx4 takes any dword alignment)
+    static BS_FN void gload128(const void *p, V off, V (&w)[4])
+    {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4)));
+        const u4 v = *reinterpret_cast<const u4 *>(static_cast<const char *>(p) + off);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    }
+    BS_FN void lds_write128(V addr, const V (&w)[4])                    // 16-byte aligned
+    {
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u4a *>(lds + addr) = u4a{w[0], w[1], w[2], w[3]};
+    }
     static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off) = v; }
     static BS_FN void gstore8(void *p, V off, V v, V pred) { if (pred) static_cast<uint8_t *>(p)[off] = (uint8_t)v; }
     // lane-wise select by a 64-bit lane mask: one v_cndmask_b32 with the mask in an SGPR pair, no plane of the mask in a register

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 
 #define BS_FN inline
@@ -82,6 +83,14 @@ struct EmuBackend {
         return r;
     }
     static V gload32(const void *p, const V &off) { V r; for (int i = 0; i < 64; ++i) std::memcpy(&r.l[i], (const char *)p + off.l[i], 4); return r; }
+    static void gload128(const void *p, const V &off, V (&w)[4]) { for (int i = 0; i < 64; ++i) for (int k = 0; k < 4; ++k) std::memcpy(&w[k].l[i], (const char *)p + off.l[i] + 4 * k, 4); }
+    void lds_write128(const V &addr, const V (&w)[4])
+    {
+        for (int i = 0; i < 64; ++i) {
+            if (addr.l[i] % 16) throw std::runtime_error("ds_write_b128 at an address that is not 16-byte aligned");
+            for (int k = 0; k < 4; ++k) { (void)lds_().at(addr.l[i] + 4 * k + 3); std::memcpy(&lds_().at(addr.l[i] + 4 * k), &w[k].l[i], 4); }
+        }
+    }
     static void gstore32(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) std::memcpy((char *)p + off.l[i], &v.l[i], 4); }
     static void gstore8(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) ((uint8_t *)p)[off.l[i]] = (uint8_t)v.l[i]; }
     static V select_lanes(uint64_t m, const V &a, const V &b) { V r; for (int i = 0; i < 64; ++i) r.l[i] = ((m >> i) & 1) ? a.l[i] : b.l[i]; return r; }
