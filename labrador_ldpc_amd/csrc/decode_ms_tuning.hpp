@@ -12,7 +12,7 @@
     defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
     defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
     defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH) || defined(LDPC_DIAG_NOCAP_ONLY) || defined(LDPC_PAIR_ARRIVE_WAIT)
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH) || defined(LDPC_DIAG_NOCAP_ONLY) || defined(LDPC_PAIR_ARRIVE_WAIT) || defined(LDPC_PAIR_LLR_DMA) || defined(LDPC_PAIR_FLAG_SETS)
 #error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
 #endif
 #endif
@@ -132,6 +132,18 @@
 #endif
 #ifndef LDPC_PAIR_ODD_B64
 #define LDPC_PAIR_ODD_B64 -1
+#endif
+// Round 5 (the per-codeword fixed cost, DESIGN.md / profiles/r05_kbench/f32_fixed_cost.txt): the NEXT codeword's LLRs are brought into
+// LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no wait inside the iterations) during iteration 1 of the current decode,
+// instead of register loads issued behind the last iteration whose HBM latency the prologue then waits for.  f32 only (4-byte LLRs).
+// -1 = per type, 0 / 1 = force.
+#ifndef LDPC_PAIR_LLR_DMA
+#define LDPC_PAIR_LLR_DMA -1
+#endif
+// Round 5: flags, clamp vote and next-codeword word double-buffered by the codeword's parity, which makes the workgroup barrier behind the
+// epilogue unnecessary (without LLR_DMA only: the DMA's landing needs that barrier).  0 = off.
+#ifndef LDPC_PAIR_FLAG_SETS
+#define LDPC_PAIR_FLAG_SETS 0
 #endif
 // Wave priority over the six (check row, index) steps of the check phase; 3 before them.  A dozen
 // alternatives, also per quarter, measured 6.4-6.75 against 6.75 for this one.

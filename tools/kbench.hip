@@ -164,6 +164,26 @@ int main()
                 printf("  wave %2d over all workgroups and iterations: check phase %llu .. %llu ticks, wait behind it %llu .. %llu\n", w, cmn, cmx, wmn, wmx);
             }
         }
+#if KPAIR
+        {   // round 5: the fixed part of a codeword, per quarter of the workgroup's waves
+            std::vector<unsigned long long> fx(256 * 16 * 8);
+            CK(hipMemcpyFromSymbol(fx.data(), HIP_SYMBOL(ldpc::g_fixed), fx.size() * 8));
+            static const char *name[7] = {"epilogue", "barrier behind it", "begin_codeword (zeroing, LLR wait, vote)", "barrier before the iterations",
+                                          "pass 0: variable phase", "pass 0: barrier", "pass 0: check phase + ticket"};
+            double all[8] = {};
+            for (int q = 0; q < 4; ++q) {
+                double sq[8] = {};
+                for (int b = 0; b < 256; ++b) for (int w = 4 * q; w < 4 * q + 4; ++w) for (int k = 0; k < 8; ++k) sq[k] += fx[(b * 16 + w) * 8 + k];
+                printf("  fixed part, quarter %d waves (ticks per codeword):", q);
+                for (int k = 0; k < 7; ++k) { printf(" %5.0f", sq[k] / sq[7]); all[k] += sq[k]; }
+                all[7] += sq[7];
+                printf("\n");
+            }
+            double sum = 0;
+            for (int k = 0; k < 7; ++k) { printf("  fixed part: %-42s %6.0f ticks per codeword\n", name[k], all[k] / all[7]); sum += all[k] / all[7]; }
+            printf("  fixed part: total %.0f ticks per codeword (the stamped iterations above exclude pass 0)\n", sum);
+        }
+#endif
         for (int q = 0; q < 4; ++q)
             printf("  quarter %d waves: variable %.0f | wait2 %.0f | check %.0f | wait1 %.0f\n", q, perq[q][0] / 1024 / (iters_total / 256), perq[q][1] / 1024 / (iters_total / 256),
                    perq[q][2] / 1024 / (iters_total / 256), perq[q][3] / 1024 / (iters_total / 256));
