@@ -42,26 +42,17 @@
 
 #define LDPC_INLINE __attribute__((always_inline))
 
-#include "decode_ms_tuning.hpp"    // tuned settings; experiment overrides and LDPC_DIAG_* only under LDPC_KBENCH
+#include "decode_ms_tuning.hpp"    // tuned settings (kernel experiments and timing diagnostics: tools/kbench/)
 
-#ifdef LDPC_DIAG_NOBARRIER
-#define LDPC_SYNC() __builtin_amdgcn_s_waitcnt(0)
-#else
 // Workgroup barrier for LDS hand-offs.  Written out (instead of __syncthreads()) so that it waits
 // for LDS operations only and not for the asynchronous LLR staging copies counted in vmcnt.
 #define LDPC_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
 #if LDPC_PRIO == 1
 #define LDPC_SETPRIO(n) do { if constexpr (PRIO_WAVES) { __builtin_amdgcn_s_setprio(n); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #elif LDPC_PRIO == 2
 #define LDPC_SETPRIO(n) do { if constexpr (PRIO_WAVES) __builtin_amdgcn_s_setprio(n); } while (0)
 #else
 #define LDPC_SETPRIO(n) do { } while (0)
-#endif
-#ifdef LDPC_DIAG_FIXED_ITERS
-#define LDPC_DIAG_EARLY_EXIT 0
-#else
-#define LDPC_DIAG_EARLY_EXIT 1
 #endif
 #define LDPC_DEV __device__ __forceinline__
 
@@ -179,10 +170,6 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // which minNum would otherwise turn into a quiet NaN.  +inf LLRs were always part of the contract (tests since round 1).
     // (Written with the builtin, not as inline asm: an asm statement between a load and its use makes the compiler wait
     // for every LLR load on the spot -- ten serialised L2 round trips per variable phase in the register-lean kernel.)
-#ifdef LDPC_DIAG_NONAN
-    LDPC_DEV static R load(float x) { return x + 0.0f; }                         // (kbench: what does the NaN mapping cost?)
-    LDPC_DEV static R canon_late(R x) { return x + 0.0f; }
-#else
     LDPC_DEV static R load(float x) { return __builtin_fminf(x + 0.0f, __builtin_inff()); }
     // LATE canonicalisation, for the kernels where the load-time form does not come for free.  Without the NaN mapping the
     // compiler never materialised `llr = raw + 0.0`: it kept the raw registers and folded the `+ 0.0` into the copy that starts
@@ -194,7 +181,6 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     // LLR leaves a NaN marginal, which min(., inf) maps to the +inf marginal a +inf LLR would have left.  One more v_min per
     // transmitted column and iteration, no extra registers.
     LDPC_DEV static R canon_late(R x) { return __builtin_fminf(x + 0.0f, __builtin_inff()); }
-#endif
     LDPC_DEV static R keep_raw(float x) { return x; }
     LDPC_DEV static R load_nonan(float x) { return x + 0.0f; }                   // for values a vote has shown to hold no NaN
     LDPC_DEV static float store(R x) { return x; }
@@ -656,11 +642,7 @@ constexpr bool has_nocap_loop()
 {
     // (TM1536: 65.7 -> 69.2 M codewords/s with the loop and the clamp form; TM6144 loses 2 % -- its local-edge updates
     // in the variable phase keep the multiply / clamp forms out; TM1280 spills: profiles/r03_kbench/kb14.txt)
-#ifdef LDPC_NOCAP_ALSO
-    constexpr bool code = CODE == TM2048 || CODE == TC512 || CODE == TM1536 || CODE == LDPC_NOCAP_ALSO;     // (kbench experiment)
-#else
     constexpr bool code = CODE == TM2048 || CODE == TC512 || CODE == TM1536;
-#endif
     return LDPC_NOCAP != 0 && std::is_same_v<T, float> && code && Geometry_G<CODE, IPT>() == 1 && LEAN == 0 && IPT == 1;
 }
 
@@ -704,11 +686,7 @@ constexpr uint32_t NAN_MARK = 0xFFFFFFFFu;
 template <int CODE, class T, int IPT>
 constexpr uint32_t claim_chunk()
 {
-#ifdef LDPC_CLAIM_K
-    return LDPC_CLAIM_K;
-#else
     return CODE == TM2048 ? 4 : (CODE == TM5120 || CODE == TM6144) ? 2 : 1;
-#endif
 }
 
 // ---- kernel geometry -----------------------------------------------------------------------
@@ -816,13 +794,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     bool live = cw < batch;
     char *const gbase = lds + (G == 1 ? 0 : grp * GROUP_BYTES);
     auto lds_at = [&](int byte_off) LDPC_INLINE -> E & { return *reinterpret_cast<E *>(gbase + byte_off); };
-#ifdef LDPC_DIAG_NOLDS
-    auto lds_load = [&](int byte_off) LDPC_INLINE -> E { E r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(byte_off)); return r; };
-    auto lds_store = [&](int byte_off, E val) LDPC_INLINE { asm volatile("" ::"v"(byte_off), "v"(val)); };
-#else
     auto lds_load = [&](int byte_off) LDPC_INLINE -> E { return lds_at(byte_off); };
     auto lds_store = [&](int byte_off, E val) LDPC_INLINE { lds_at(byte_off) = val; };
-#endif
     auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & {
         return *reinterpret_cast<int *>(gbase + FLAG_OFF + 4 * (which & 1));
     };
@@ -925,11 +898,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // three / five registers for TM5120's ten -- instead of re-reading them from L2 in every variable phase, as the lean f32
     // kernel must (it has no registers to spare): TM5120 i8 19.04 -> 20.64 (4 dB), 7.33 -> 7.84 M codewords/s (2 dB), no spills
     // (profiles/r03_kbench/kb3.txt).  Unpacking is a shift-and-sign-extend folded into the conversion to f32.
-#ifdef LDPC_LEAN_PACKED_LLR
-    constexpr bool PACKED_LLR = LDPC_LEAN_PACKED_LLR != 0 && LEAN == 1 && sizeof(T) <= 2;
-#else
     constexpr bool PACKED_LLR = LEAN == 1 && sizeof(T) <= 2 && packed_llr_default<CODE, T>();
-#endif
     constexpr int PER_REG = PACKED_LLR ? 4 / (int)sizeof(T) : 1, PK_BITS = 8 * (int)sizeof(T);
     unsigned llr_pk[IPT][(NTX + PER_REG - 1) / PER_REG];
     auto fetch_llrs = [&](uint32_t c) LDPC_INLINE {
@@ -972,11 +941,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // that canonicalises only for codewords that have one.  The second copy alone costs more: 120 spilled registers, 13.3 M
     // codewords/s (LDPC_NANVOTE, kbench only; profiles/r03_kbench/kb16_nanvote.txt).  The vote survives as the MARK of the
     // two-pass form: the common copy is the whole first kernel, the canonicalising copy a second kernel.)
-#ifdef LDPC_NANVOTE
-    constexpr bool NANVOTE = LDPC_NANVOTE != 0 && LATE_CANON && LEAN == 1 && std::is_same_v<T, float> && G == 1;
-#else
     constexpr bool NANVOTE = false;
-#endif
     constexpr bool ZERO_FREE = PEEL_FIRST;
     auto begin_codeword = [&](bool staged) LDPC_INLINE {
         if constexpr (PF) {
@@ -1051,11 +1016,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         constexpr bool BND = decltype(BND_)::value != 0 && G == 1;
         const R nv = O::sub_nv(x, uu);                                                 // :421
         // keep nv if its sign equals the old v's or the old v is zero, else zero it (:422-425)
-#ifdef LDPC_DIAG_NOSELFCORR
-        const R nw = nv;
-#else
         const R nw = BND ? O::template self_correct_b<true, FORM_B>(nv, v[S][B]) : O::template self_correct<FORM_U>(nv, v[S][B]);
-#endif
         v[S][B] = nw;
     };
     // the part of the check update that needs no exchanged data: the LOCAL edges
@@ -1171,7 +1132,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // 5 dB (2 iterations), +1-12 % at 3 dB (min_waves_per_simd() has the table); config 2 (TC512 f32 at 2 dB, 15
     // iterations, 29 % failures) 109.5 -> 106.9.  Multi-wave codewords need one more barrier per iteration for this:
     // WG_VERDICT below.
-    constexpr bool WAVE_VERDICT = LDPC_WAVE_VERDICT && GEO::WG == 64 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
+    constexpr bool WAVE_VERDICT = LDPC_WAVE_VERDICT && GEO::WG == 64 && LEAN == 0;
     // The same for codewords of several waves needs a third barrier per iteration (parity -> flag -> barrier -> read).
     // Where several workgroups share a CU the barrier hides behind the others and the skipped half pass is a net gain:
     // TM1536 f32 59.0 -> 62.5 (3 dB; 31.6 -> 31.9 at 2 dB where most frames fail), i8 55.5 -> 57.6; TM1280 f32 67.8 ->
@@ -1181,12 +1142,12 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     // have to read its 39 marginals twice.
     constexpr int WG_VERDICT_SET = LDPC_WG_VERDICT >= 0 ? LDPC_WG_VERDICT
                                  : (CODE == TM1536 || (CODE == TM1280 && !(sizeof(T) <= 2))) ? 1 : 0;
-    constexpr bool WG_VERDICT = WG_VERDICT_SET != 0 && !WAVE_VERDICT && G == 1 && IPT == 1 && LDPC_DIAG_EARLY_EXIT && LEAN == 0;
+    constexpr bool WG_VERDICT = WG_VERDICT_SET != 0 && !WAVE_VERDICT && G == 1 && IPT == 1 && LEAN == 0;
     // The register-lean check phase cannot hold its marginals between a parity pass and the updates (that is what makes it
     // lean), but it can split the other way: pass A = requests, edge updates, parities and sign words of ALL rows; vote
     // through the flag and a third barrier; pass B = exclusive minima, next u and their stores, skipped on success (it reads
     // only v, which is in registers).  LDPC_LEAN_VERDICT: measured in round 3 (see lean_verdict_default()).
-    constexpr bool LEAN_VERDICT = (LDPC_LEAN_VERDICT >= 0 ? LDPC_LEAN_VERDICT != 0 : lean_verdict_default<CODE, T>()) && LEAN == 1 && G == 1 && LDPC_DIAG_EARLY_EXIT;
+    constexpr bool LEAN_VERDICT = (LDPC_LEAN_VERDICT >= 0 ? LDPC_LEAN_VERDICT != 0 : lean_verdict_default<CODE, T>()) && LEAN == 1 && G == 1;
     constexpr bool IN_PHASE_VERDICT = WAVE_VERDICT || WG_VERDICT || LEAN_VERDICT;
     // Iteration 0 peeled (PEEL_FIRST; at high SNR a decode is two or three passes, and the first one is cheaper than
     // the rest): u = 0 and v = 0 make every new v the marginal itself (decoder.rs:421-425
@@ -1307,11 +1268,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
                 const int sgn = xor_reduce<D>(sr), par = (WAVE_VERDICT || WG_VERDICT) ? 0 : xor_reduce<D>(xw);
-#ifdef LDPC_DIAG_NOMIN
-                static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = O::mag(a[decltype(J_)::value]); });
-#else
                 exclusive_min<O, D, true, CAP>(a, e);                                       // :391-395, :430-435
-#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
@@ -1595,7 +1552,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
         // verdict on the previous iteration (decoder.rs:453-463, :466-474)
         if (!done) {
             if constexpr (!IN_PHASE_VERDICT) {
-                if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
+                if (it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }
             }
             if (!done && it == maxiters) { done = true; }
         }
@@ -1615,12 +1572,8 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     };
     LDPC_SYNC();                  // the zeroed exchange slots, the flags and the clamp vote are visible
     if constexpr (NOCAP_POSSIBLE || NANVOTE) {
-#ifdef LDPC_DIAG_NOCAP_ONLY
-        iterate(IC<0>{});             // (timing diagnostic: the clamp-free copy of the loop alone -- what would a two-kernel split of the clamp modes buy?)
-#else
         if (GEO::WG == 64 ? cap_wave : __builtin_amdgcn_readfirstlane(cap_flag()) != 0) iterate(IC<1>{});
         else iterate(IC<0>{});
-#endif
     } else {
         iterate(IC<1>{});
     }
@@ -1710,9 +1663,6 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
 template <int CODE, class T, int IPT, int LEAN>
 constexpr int min_waves_per_simd()
 {
-#ifdef LDPC_MINW_CODE                                  // (tools/kbench.hip experiments)
-    if (CODE == LDPC_MINW_CODE) return LDPC_MINW;
-#endif
     // f64 on TC128 / TC256: 252-253 registers in round 2, 264-268 with round 3's additions -- one wave per SIMD instead of
     // two (694 -> 487, 383 -> 252 M codewords/s); held at 256
     if (sizeof(T) > 4) return (CODE <= TC256 && IPT == 1 && LEAN == 0) ? 2 : 1;

@@ -26,19 +26,6 @@
 
 namespace ldpc {
 
-#ifdef LDPC_DIAG_STAMPS
-// per wave: cycles in [variable phase, wait at barrier 2, check phase, wait at barrier 1], summed over iterations
-// [4] = ticks from the first begin_codeword to the end of the last epilogue, [5] = the same in s_memrealtime (100 MHz) ticks
-__device__ unsigned long long g_stamps[256 * 16 * 6];
-// per wave: [0] the longest and [1] the shortest check phase seen, [2] the longest wait at the barrier behind it, [3] the shortest
-__device__ unsigned long long g_stamp_ext[256 * 16 * 4];
-// absolute s_memrealtime at workgroup entry / at the start of the codeword loop / at exit, last launch only
-__device__ unsigned long long g_wg_times[256 * 3];
-// round 5: the per-codeword FIXED part, per wave, summed over codewords: [0] epilogue (fetch issue, ballots, packing, stores),
-// [1] barrier behind it, [2] begin_codeword (zeroing, LLR wait, range vote), [3] barrier before the iterations, [4] variable phase of
-// the peeled pass 0, [5] barrier behind it, [6] check phase of pass 0 (+ the queue ticket), [7] codewords counted
-__device__ unsigned long long g_fixed[256 * 16 * 8];
-#endif
 
 typedef float ldpc_f2 __attribute__((ext_vector_type(2)));
 
@@ -49,11 +36,7 @@ struct PairGeometry {
     static constexpr int NX = count_exchanged(*CODES[CODE].proto);
     static constexpr int NXC = count_exch_cols(*CODES[CODE].proto);
     static constexpr int OUT_LEN = CODES[CODE].output_len();
-    // the next codeword's LLRs arrive by LDS-DMA (LDPC_PAIR_LLR_DMA, decode_ms_tuning.hpp): 4-byte LLR types only
-    static constexpr bool LLR_DMA = LDPC_PAIR_LLR_DMA >= 0 ? (LDPC_PAIR_LLR_DMA != 0 && sizeof(T) == 4) : false;
-    static constexpr int LLR_OFF = ((NX + NXC) * M * 4 + 32 + 1023) / 1024 * 1024;                                     // (1 KiB pieces)
-    static constexpr int LDS_BYTES = LLR_DMA ? LLR_OFF + CODES[CODE].n * 4
-                                             : ((NX + NXC) * M * 4 + 8 + 15) / 16 * 16 + (LDPC_PAIR_ARRIVE_WAIT ? 16 : 0);     // (+ four arrive counters)
+    static constexpr int LDS_BYTES = ((NX + NXC) * M * 4 + 16 + 15) / 16 * 16;      // exchange slots + two flags, the clamp vote, the next-codeword word
     static_assert(M % 512 == 0 && NT <= 1024, "pair ownership needs M/8 >= 64 lanes per quarter and <= 1024 threads");
 };
 
@@ -108,28 +91,8 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
 
     auto lds1 = [&](int off) LDPC_INLINE -> float & { return *reinterpret_cast<float *>(lds + off); };
     auto lds2 = [&](int off) LDPC_INLINE -> ldpc_f2 & { return *reinterpret_cast<ldpc_f2 *>(lds + off); };
-    // LDPC_PAIR_FLAG_SETS: two sets of (flag 0, flag 1, clamp vote), used by alternate codewords of the workgroup (`fset` = 0 / 16)
-    constexpr bool FLAG_SETS = LDPC_PAIR_FLAG_SETS != 0;
-    static_assert(!(FLAG_SETS && (GEO::LLR_DMA || LDPC_PAIR_ARRIVE_WAIT)), "the flag sets drop the barrier the LLR DMA's landing needs");
-    int fset = 0;
-    auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + fset + 4 * (which & 1)); };
-    auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + fset + 8); };
-    auto cap_flag_other = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + (fset ^ 16) + 8); };
-    // LDPC_PAIR_ARRIVE_WAIT: arrive counters (per quarter of the workgroup) behind the flag words; `arrivals` = variable phases so far
-    auto arrive_word = [&](int qtr) LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 16 + 4 * qtr); };
-    uint32_t arrivals = 0;
-    constexpr int WAVES_PER_QUARTER = GEO::NT / 64 / 4;
-    auto arrive = [&]() LDPC_INLINE {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's marginal stores have landed
-        if ((t & 63) == 0) __hip_atomic_fetch_add(&arrive_word(LDPC_PAIR_ARRIVE_WAIT == 2 ? t / (GEO::NT / 4) : 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ++arrivals;
-    };
-    auto wait_for = [&](int qtr) LDPC_INLINE {                               // until every wave (of quarter qtr) has arrived `arrivals` times
-        const int want = (int)arrivals * (LDPC_PAIR_ARRIVE_WAIT == 2 ? WAVES_PER_QUARTER : 4 * WAVES_PER_QUARTER);
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arrive_word(LDPC_PAIR_ARRIVE_WAIT == 2 ? qtr : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
-            __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    };
+    auto flag_at = [&](uint32_t which) LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 4 * (which & 1)); };
+    auto cap_flag = [&]() LDPC_INLINE -> int & { return *reinterpret_cast<int *>(lds + FLAG_OFF + 8); };
     constexpr bool NOCAP_POSSIBLE = LDPC_PAIR_NOCAP && std::is_same_v<T, float>;
 
     // Rotation of block B for this body's quarter JW: phi, and where the even/odd split puts the edges.
@@ -148,9 +111,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     T lraw[IPT][NTX];
 
     auto fetch_llrs = [&](uint32_t c) LDPC_INLINE {
-#ifdef LDPC_DIAG_NOFETCH
-        if (c != blockIdx.x) return;             // (timing diagnostic: every codeword of a workgroup re-uses the first one's LLRs)
-#endif
         unsigned tu = (unsigned)t;
         asm volatile("" : "+v"(tu));
         const uint32_t cc = c < batch ? c : batch - 1;
@@ -162,39 +122,10 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         });
     };
 
-    // LDPC_PAIR_LLR_DMA: codeword c's n LLRs -> LDS [LLR_OFF, + 4 n) as they lie in memory, 1 KiB per wave instruction (the
-    // destination of an LDS-DMA is wave-uniform base + 16 x lane), two instructions per wave; nothing is waited for here.
-    constexpr bool LLR_DMA = GEO::LLR_DMA;
-    auto dma_llrs = [&](uint32_t c) LDPC_INLINE {
-        static_assert(!LLR_DMA || (N * 4) % (16 * 1024) == 0, "16 waves x 1 KiB pieces");
-        const uint32_t cc = c < batch ? c : batch - 1;
-        const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const unsigned lane = threadIdx.x & 63u;
-        constexpr int PIECES = N * 4 / 1024 / (NT / 64);
-        static_for<0, PIECES>([&](auto J_) LDPC_INLINE {
-            const unsigned piece = wave * PIECES + decltype(J_)::value;
-            const char *src = reinterpret_cast<const char *>(llrs + (size_t)cc * N) + piece * 1024u + lane * 16u;
-            const unsigned dst = (unsigned)(uintptr_t)(lds + GEO::LLR_OFF) + piece * 1024u;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        });
-    };
-
     auto begin_codeword = [&]() LDPC_INLINE {
         int tq = t;
         asm volatile("" : "+v"(tq));             // opaque per phase (no address hoisting), but visibly a multiple of 8 below
         const int tb8 = tq * 8;
-        if constexpr (LLR_DMA) {
-            // (the LLRs landed in LDS during the previous decode: every wave waited for its own pieces before the barrier behind
-            // the epilogue)
-            static_for<0, NTX>([&](auto C_) LDPC_INLINE {
-                constexpr int C = decltype(C_)::value;
-                const ldpc_f2 p = lds2(GEO::LLR_OFF + C * M * 4 + tb8);
-                lraw[0][C] = (T)p.x;
-                lraw[1][C] = (T)p.y;
-            });
-        }
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {
             constexpr int S = decltype(S_)::value;
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
@@ -205,21 +136,16 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             static_for<0, NCOLS>([&](auto C_) LDPC_INLINE { va[S][decltype(C_)::value] = O::zero(); });
             static_for<0, NTX>([&](auto C_) LDPC_INLINE { llr[S][decltype(C_)::value] = O::load(lraw[S][decltype(C_)::value]); });
         });
-#ifndef LDPC_DIAG_NOZERO
         if constexpr (!LDPC_PAIR_PEEL_FIRST)
         static_for<0, NX>([&](auto X_) LDPC_INLINE {                                   // u = 0 in every exchange slot
             lds2(lds_xu_off(P, decltype(X_)::value, BLK_BYTES) + tb8) = ldpc_f2{0.0f, 0.0f};
         });
-#endif
         if (t < 2) flag_at(t) = 0;
-        if constexpr (FLAG_SETS) { if (t == 2) cap_flag_other() = 0; }       // the NEXT codeword's vote word (nobody reads or votes it during this decode)
-        if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) { if (t >= 4 && t < 8) arrive_word(t - 4) = 0; arrivals = 0; }
         // f32: the clamp of the exclusive minimum at FLT_MAX (decoder.rs:414-415) can only bite if some
         // magnitude reaches FLT_MAX, i.e. if an LLR is infinite or so large that sums overflow.  With every
         // |LLR| <= nocap_limit (derived from max_iters by the host: nocap_limit_for(), decode_ms_launch.hpp)
         // nothing can, and the check phase runs without the clamp operations (8 of 76 min-class
         // instructions per thread and iteration).
-#ifndef LDPC_DIAG_NOVOTE
         if constexpr (NOCAP_POSSIBLE) {
             bool big = false;
             static_for<0, IPT>([&](auto S_) LDPC_INLINE {
@@ -230,7 +156,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             });
             if (__ballot(big) != 0 && (t & 63) == 0) cap_flag() = 1;
         }
-#endif
     };
 
     // BND_: the codeword passed the LLR range vote (it runs the clamp-free copy of the loop), which also makes
@@ -238,15 +163,11 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     auto edge_update = [&](auto S_, auto B_, R x, auto BND_) LDPC_INLINE {
         constexpr int S = decltype(S_)::value, B = decltype(B_)::value;
         const R nv = O::sub_nv(x, u[S][B]);                                            // :421
-#ifdef LDPC_DIAG_NOSELFCORR
-        v[S][B] = nv;
-#else
         // the clamp forms need a guarantee about the values: integer messages always have it, f32 only the codewords of the
         // clamp-free loop (they passed the range vote)
         constexpr bool BND = decltype(BND_)::value != 0;
         constexpr int F = (FORM >= 2 && (BND || sizeof(T) <= 2)) ? FORM : (LDPC_PAIR_SELFCORR_CARRY != 0 ? 1 : 0);
         v[S][B] = O::template self_correct_b<BND, F>(nv, v[S][B]);                     // :422-425
-#endif
     };
 
     // ---- variable phase: marginals (decoder.rs:382-383, :408) -------------------------------------
@@ -312,7 +233,6 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             constexpr int B = decltype(B_)::value;
             constexpr int slot = exch_slot(P, B);
             if constexpr (slot >= 0) {
-                if constexpr (LDPC_PAIR_ARRIVE_WAIT == 2) wait_for(((t / (GEO::NT / 4)) + theta_of(P.blk[B].val)) & 3);      // the quarter this block's marginals were written by
                 constexpr int cs = col_slot(P, P.blk[B].col);
                 constexpr int off = lds_xva_off(P, cs, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
                 if constexpr (even_c(B)) {
@@ -349,16 +269,9 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
             });
         });
         };
-        if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) {
-            local_edges();                         // needs the thread's own marginals only: runs while the other waves arrive
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LDPC_PAIR_ARRIVE_WAIT == 1) wait_for(0);
-            request_marginals();
-        } else {
-            request_marginals();
-            __builtin_amdgcn_sched_barrier(0);
-            local_edges();
-        }
+        request_marginals();
+        __builtin_amdgcn_sched_barrier(0);
+        local_edges();
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, IPT>([&](auto S_) LDPC_INLINE {                                  // (3) exchanged edges
             static_for<0, NB>([&](auto B_) LDPC_INLINE {
@@ -391,24 +304,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                     if constexpr (exch_slot(P, B) >= 0) xw[J] = O::bits(xs[S][B]);     // :445-447
                     else xw[J] = O::bits(va[S][P.blk[B].col]);
                 });
-#ifdef LDPC_DIAG_NOPAR
-                const int sgn = xor_reduce<D>(sr), par = xw[0];
-#else
                 const int sgn = xor_reduce<D>(sr), par = xor_reduce<D>(xw);
-#endif
-#ifdef LDPC_DIAG_NOMIN
-                static_for<0, D>([&](auto J_) LDPC_INLINE { e[decltype(J_)::value] = a[(decltype(J_)::value + 1) % D]; });
-#else
                 exclusive_min<O, D, true, CAP>(a, e);                                  // :391-395, :430-435
-#endif
                 static_for<0, D>([&](auto J_) LDPC_INLINE {
                     constexpr int J = decltype(J_)::value;
                     constexpr int B = row_block(P, Rw, J);
-#ifdef LDPC_DIAG_NOSIGN
-                    u[S][B] = e[J];
-#else
                     u[S][B] = O::apply_sign(e[J], sgn, sr[J]);                         // :398-405
-#endif
                     constexpr int slot = exch_slot(P, B);
                     if constexpr (slot >= 0) {
                         constexpr int off = lds_xu_off(P, slot, BLK_BYTES) - lds_bias(P, B, BLK_BYTES);
@@ -423,14 +324,7 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     };
 
     // ---- persistent loop over codewords ----------------------------------------------------------------
-#ifdef LDPC_DIAG_STAMPS
-    if (t == 0 && blockIdx.x < 256) g_wg_times[blockIdx.x * 3] = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (t == 0) { cap_flag() = 0; if constexpr (FLAG_SETS) cap_flag_other() = 0; }
-    if constexpr (LLR_DMA) {                     // the first codeword's LLRs: issued, waited for, and the barrier below makes them visible
-        if (blockIdx.x < n_groups) dma_llrs(blockIdx.x);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (t == 0) cap_flag() = 0;
     LDPC_SYNC();
     // Where the next codeword's LLR loads are issued: before this one's epilogue (f32: 7.35 -> 7.66 M codewords/s, the
     // epilogue covers part of their latency) or at the top of its own turn (i8 / i16: the early loads' raw bytes are
@@ -438,18 +332,15 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
     // registers against 3, 6.99 -> 7.09; fetching a column's two adjacent narrow LLRs with ONE load into ONE register halves
     // what the early fetch keeps alive, and still spills 23 registers against 6: 8.00 -> 7.71, profiles/r03_kbench/
     // kb22_pair_packed_fetch.txt).  LDPC_PAIR_FETCH_EARLY: -1 = per type, 0 / 1 = force.
-    constexpr bool FETCH_EARLY = !LLR_DMA && (LDPC_PAIR_FETCH_EARLY >= 0 ? LDPC_PAIR_FETCH_EARLY != 0 : sizeof(T) >= 4);
+    constexpr bool FETCH_EARLY = LDPC_PAIR_FETCH_EARLY >= 0 ? LDPC_PAIR_FETCH_EARLY != 0 : sizeof(T) >= 4;
     if (FETCH_EARLY && blockIdx.x < n_groups) fetch_llrs(blockIdx.x);
-#ifdef LDPC_DIAG_STAMPS
-    const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime(), loop_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // Dynamic distribution of the codewords (claim != nullptr): see decode_ms_body in decode_ms_kernel.hpp.  Thread 0
     // draws a ticket at the start of each decode; the codeword it names, gridDim.x + ticket, is this workgroup's NEXT
     // one.  The returning register is collected after the first pass (collect_claim) into one LDS word, which every wave
     // reads when the decode ends -- many barriers later -- in time for the early LLR fetch.
     const bool dyn = claim != nullptr && maxiters != 0;
     uint32_t ticket = 0;
-    int *const next_word = reinterpret_cast<int *>(lds + FLAG_OFF + 12);            // (FLAG_SETS: set 0's fourth word; one is enough)
+    int *const next_word = reinterpret_cast<int *>(lds + FLAG_OFF + 12);
     auto collect_claim = [&]() LDPC_INLINE {
         if constexpr (JW == 0) {
             if (dyn && t == 0) {
@@ -463,87 +354,31 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         if constexpr (JW == 0) {
             if (dyn && t == 0) ticket = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if constexpr (!FETCH_EARLY && !LLR_DMA) fetch_llrs(cw);   // (FETCH_EARLY: this codeword's LLR loads were issued behind the previous epilogue)
-#ifdef LDPC_DIAG_STAMPS
-        const unsigned long long f2 = __builtin_amdgcn_s_memtime();
-#endif
+        if constexpr (!FETCH_EARLY) fetch_llrs(cw);   // (FETCH_EARLY: this codeword's LLR loads were issued behind the previous epilogue)
         begin_codeword();
-#ifdef LDPC_DIAG_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long f3 = __builtin_amdgcn_s_memtime();
-        unsigned long long f4 = 0, f5 = 0, f6 = 0, f7 = 0;
-#endif
-        bool done = false, ok = false, dma_issued = false;
-        (void)dma_issued;
+        bool done = false, ok = false;
         uint32_t iters = maxiters;
-#ifdef LDPC_DIAG_STAMPS
-        unsigned long long acc_var = 0, acc_w2 = 0, acc_chk = 0, acc_w1 = 0, t3 = __builtin_amdgcn_s_memtime();
-        unsigned long long chk_max = 0, chk_min = ~0ull, w1_max = 0, w1_min = ~0ull;
-#endif
         // the iterations, as one loop per clamp mode (two check phases inside ONE loop cost 330 spilled VGPRs)
         auto iterate = [&](auto CAP_) LDPC_INLINE {
             uint32_t it0 = 0;
             if constexpr (LDPC_PAIR_PEEL_FIRST != 0) {
                 if (maxiters == 0) { done = true; return; }
-#ifdef LDPC_DIAG_STAMPS
-                f4 = __builtin_amdgcn_s_memtime();
-#endif
                 variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{}, IC<1>{});
-#ifdef LDPC_DIAG_STAMPS
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                f5 = __builtin_amdgcn_s_memtime();
-#endif
-                if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) arrive(); else LDPC_SYNC();
-#ifdef LDPC_DIAG_STAMPS
-                f6 = __builtin_amdgcn_s_memtime();
-#endif
+                LDPC_SYNC();
                 check_phase(0u, CAP_, IC<1>{});
                 collect_claim();
-#ifdef LDPC_DIAG_STAMPS
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                f7 = t3 = __builtin_amdgcn_s_memtime();
-#endif
                 it0 = 1;
             }
             for (uint32_t it = it0;; ++it) {
                 if (it > 0) LDPC_SYNC();          // (the barrier before iteration 0 is taken below, before the clamp mode is read)
-                if constexpr (LLR_DMA) {
-                    // The NEXT codeword's LLRs set out for LDS now: every wave has taken this codeword's LLRs into registers (two
-                    // barriers ago), the next codeword is known (the queue's ticket was collected behind the first pass and the
-                    // barrier above made it visible), and a whole iteration -- a decode that ends here is a clean frame -- lies
-                    // ahead to cover the HBM latency.  No register is held, nothing inside the iterations waits for it.
-                    if (it == 1) {
-                        const uint32_t nx = dyn ? (uint32_t)__builtin_amdgcn_readfirstlane(*next_word) : g + gridDim.x;
-                        if (nx < n_groups) dma_llrs(nx);
-                        dma_issued = true;
-                    }
-                }
-#ifdef LDPC_DIAG_STAMPS
-                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                if (it > 0) { acc_w1 += t0 - t3; if (t0 - t3 > w1_max) w1_max = t0 - t3; if (t0 - t3 < w1_min) w1_min = t0 - t3; }
-#endif
-                if (LDPC_DIAG_EARLY_EXIT && it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
+                if (it > 0 && flag_at(it - 1) == 0) { done = true; ok = true; iters = it - 1; }   // :453-463
                 else if (it == maxiters) { done = true; }
                 if (done) break;
                 variable_phase(IC<(decltype(CAP_)::value == 0 && NOCAP_POSSIBLE) ? 1 : 0>{}, IC<0>{});
-#ifdef LDPC_DIAG_STAMPS
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-#endif
-                if constexpr (LDPC_PAIR_ARRIVE_WAIT != 0) arrive(); else LDPC_SYNC();
-#ifdef LDPC_DIAG_STAMPS
-                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-#endif
+                LDPC_SYNC();
                 if (it > 0 && t == 0) flag_at(it - 1) = 0;
                 check_phase(it, CAP_, IC<0>{});
                 if constexpr (LDPC_PAIR_PEEL_FIRST == 0) { if (it == 0) collect_claim(); }
-#ifdef LDPC_DIAG_STAMPS
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                t3 = __builtin_amdgcn_s_memtime();
-                acc_var += t1 - t0; acc_w2 += t2 - t1; acc_chk += t3 - t2;
-                if (t3 - t2 > chk_max) chk_max = t3 - t2;
-                if (t3 - t2 < chk_min) chk_min = t3 - t2;
-#endif
             }
         };
         LDPC_SYNC();                              // the zeroed exchange slots, the flags and the clamp vote are visible
@@ -553,36 +388,12 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
         } else {
             iterate(IC<1>{});
         }
-#ifdef LDPC_DIAG_STAMPS
-        if ((t & 63) == 0 && blockIdx.x < 256) {
-            unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 6;
-            d[0] += acc_var; d[1] += acc_w2; d[2] += acc_chk; d[3] += acc_w1;
-            unsigned long long *x = g_stamp_ext + ((size_t)blockIdx.x * 16 + t / 64) * 4;
-            if (chk_max > x[0]) x[0] = chk_max;
-            if (x[1] == 0 || chk_min < x[1]) x[1] = chk_min;
-            if (w1_max > x[2]) x[2] = w1_max;
-            if (x[3] == 0 || w1_min < x[3]) x[3] = w1_min;
-        }
-#endif
-#ifdef LDPC_DIAG_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // (the bookkeeping above is not the epilogue's)
-        const unsigned long long f0 = __builtin_amdgcn_s_memtime();                   // the iterations are over
-#endif
         // the next codeword's LLR loads, issued before this one's epilogue (fixed cost per codeword 2.55 -> 2.12 us)
         const uint32_t g_next = dyn ? (uint32_t)__builtin_amdgcn_readfirstlane(*next_word) : g + gridDim.x;
         if (FETCH_EARLY && g_next < n_groups) fetch_llrs(g_next);
-        if constexpr (LLR_DMA) {
-            if (!dma_issued && g_next < n_groups) dma_llrs(g_next);          // (max_iters 0: no iteration 1 to issue it in)
-            // this wave's pieces have landed (they set out at least an iteration ago); the barrier behind the epilogue makes every
-            // wave's pieces visible to all.  BEFORE the epilogue's stores: on gfx9 they count in vmcnt too.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         // hard decisions, MSB first (decoder.rs:455-461 / :467-473): lane l of a wave holds positions
         // 128w + 2l and 128w + 2l + 1, so the two ballots are interleaved bit by bit (scalar unit:
         // s_bitreplicate doubles every bit), then bit-reversed per byte
-#ifdef LDPC_DIAG_NOPACK
-        if (maxiters == 0x7FFFFFFF)
-#endif
         static_for<0, NCOLS>([&](auto C_) LDPC_INLINE {
             constexpr int C = decltype(C_)::value;
             const unsigned long long ev = __ballot(O::bits(va[0][C]) < 0), od = __ballot(O::bits(va[1][C]) < 0);
@@ -604,31 +415,10 @@ LDPC_DEV void decode_ms_pair_body(const T *__restrict__ llrs, uint8_t *__restric
                 dst[1] = w[1];
             }
         });
-        if (t == 0) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; if constexpr (!FLAG_SETS) cap_flag() = 0; }
-        // The barrier behind the epilogue keeps a fast wave's next begin_codeword (flag and vote resets) away from a slow wave that
-        // still reads this codeword's verdict; with FLAG_SETS the next codeword uses the other set of words and needs none: the
-        // exchange slots are written again only behind the next codeword's own first barrier, and the word naming the next codeword
-        // is rewritten only behind a barrier every wave of this epilogue has to pass first.
-#ifdef LDPC_DIAG_STAMPS
-        const unsigned long long f1 = __builtin_amdgcn_s_memtime();
-#endif
-        if constexpr (FLAG_SETS) fset ^= 16; else LDPC_SYNC();
-#ifdef LDPC_DIAG_STAMPS
-        const unsigned long long f1b = __builtin_amdgcn_s_memtime();
-        if ((t & 63) == 0 && blockIdx.x < 256) {
-            unsigned long long *d = g_fixed + ((size_t)blockIdx.x * 16 + t / 64) * 8;
-            d[0] += f1 - f0; d[1] += f1b - f1; d[2] += f3 - f2; d[3] += f4 - f3; d[4] += f5 - f4; d[5] += f6 - f5; d[6] += f7 - f6; d[7] += 1;
-        }
-#endif
+        if (t == 0) { iters_out[cw] = iters; success_out[cw] = ok ? 1 : 0; cap_flag() = 0; }
+        LDPC_SYNC();
         g = g_next;
     }
-#ifdef LDPC_DIAG_STAMPS
-    if ((t & 63) == 0 && blockIdx.x < 256) {
-        unsigned long long *d = g_stamps + ((size_t)blockIdx.x * 16 + t / 64) * 6;
-        d[4] += __builtin_amdgcn_s_memtime() - loop_t0; d[5] += __builtin_amdgcn_s_memrealtime() - loop_r0;
-        if (t == 0) { g_wg_times[blockIdx.x * 3 + 1] = loop_r0; g_wg_times[blockIdx.x * 3 + 2] = __builtin_amdgcn_s_memrealtime(); }
-    }
-#endif
 }
 
 // Self-correction form of the pair kernel.  The clamp forms (Ops<float>::clamp_to_side) replace the compare and the select by

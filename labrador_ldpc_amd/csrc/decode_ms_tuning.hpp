@@ -1,19 +1,18 @@
 // decode_ms_tuning.hpp -- the tuned settings of the min-sum kernels, in one place.
 //
-// A LIBRARY build uses exactly the values below.  They can be overridden -- and the LDPC_DIAG_* timing
-// diagnostics, which produce WRONG decodes, enabled -- only in a translation unit that defines LDPC_KBENCH
-// before including the kernels, which tools/kbench.hip (the same-process A/B timing tool) does and the
-// library's Makefile never does: a stray -DLDPC_... in EXTRA stops the build here instead of shipping a
-// mistuned or broken decoder.
+// A LIBRARY build uses exactly the values below: a stray -DLDPC_... in the build's flags stops it here instead of shipping a mistuned
+// decoder.  Same-process A/B experiments on these settings, and the timing diagnostics that leave pieces of the decoder out, live
+// outside the library: tools/kbench/ applies its overlay (tools/kbench/diag_overlay.patch) to a COPY of these sources and builds its
+// own binaries from that (tools/kb_build.sh); nothing of it is visible to the library's translation units.
 #pragma once
 
-#ifndef LDPC_KBENCH
-#if defined(LDPC_DIAG_NOBARRIER) || defined(LDPC_DIAG_FIXED_ITERS) || defined(LDPC_DIAG_NOLDS) || defined(LDPC_DIAG_NOSELFCORR) || \
-    defined(LDPC_DIAG_NOMIN) || defined(LDPC_DIAG_NOPACK) || defined(LDPC_DIAG_NOVOTE) || defined(LDPC_DIAG_NOZERO) || defined(LDPC_DIAG_STAMPS) || defined(LDPC_DIAG_NOSIGN) || defined(LDPC_DIAG_NOPAR) || defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || \
-    defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || defined(LDPC_PRIO_ROWS_LEAN) || \
-    defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_MINW_CODE) || defined(LDPC_MINW) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
-    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_CLAIM_K) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_PACKED_LLR) || defined(LDPC_NOCAP_ALSO) || defined(LDPC_DIAG_NONAN) || defined(LDPC_NANVOTE) || defined(LDPC_LEAN_CH) || defined(LDPC_DIAG_NOCAP_ONLY) || defined(LDPC_PAIR_ARRIVE_WAIT) || defined(LDPC_PAIR_LLR_DMA) || defined(LDPC_PAIR_FLAG_SETS)
-#error "LDPC_* tuning / diagnostic switches are for tools/kbench.hip only (it defines LDPC_KBENCH); the library is built with the tuned defaults"
+#ifndef LDPC_TUNING_OVERRIDES_ALLOWED
+#if defined(LDPC_QUARTER_SPECIALISE) || defined(LDPC_NOCAP) || defined(LDPC_LOCAL_IN_VAR) || defined(LDPC_PRIO) || defined(LDPC_PRIO_ROWS) || \
+    defined(LDPC_PRIO_ROWS_LEAN) || defined(LDPC_PRIO_VAR) || defined(LDPC_TM2048_WAVES) || defined(LDPC_PAIR_LOCAL_IN_VAR) || defined(LDPC_PAIR_NOCAP) || \
+    defined(LDPC_PAIR_ODD_B64) || defined(LDPC_PRIO_ROWS_PAIR) || defined(LDPC_SELFCORR_CARRY) || defined(LDPC_WAVE_VERDICT) || defined(LDPC_WG_VERDICT) || \
+    defined(LDPC_PEEL_FIRST) || defined(LDPC_PAIR_PEEL_FIRST) || defined(LDPC_PAIR_FETCH_EARLY) || defined(LDPC_PAIR_SELFCORR_CARRY) || \
+    defined(LDPC_SELFCORR_MED3) || defined(LDPC_PAIR_SELFCORR_MED3) || defined(LDPC_LEAN_VERDICT) || defined(LDPC_LEAN_CH)
+#error "the LDPC_* tuning switches are fixed in a library build (kernel experiments: tools/kbench/)"
 #endif
 #endif
 
@@ -123,34 +122,12 @@
 #endif
 // Odd rotations read their two marginals as halves of two aligned 64-bit pairs: -1 = the default (on: i8/i16 8.0 -> 9.0 in
 // round 1; f32 7.05 -> 6.90 then, 8.33 -> 8.44 with round 3's check phase), 0 / 1 = force.
-// Round 4 experiment (profiles/r04_kbench/arrive_wait.txt): the workgroup barrier between the variable and the
-// check phase as arrive (one LDS atomic per wave) + wait (poll before the first read of an exchanged marginal), with the check
-// phase's local-edge updates in between.  1 = one counter for the workgroup, 2 = one per quarter and each block waits only for the
-// quarter its marginals come from.  Both slower than the barrier: off.
-#ifndef LDPC_PAIR_ARRIVE_WAIT
-#define LDPC_PAIR_ARRIVE_WAIT 0
-#endif
 #ifndef LDPC_PAIR_ODD_B64
 #define LDPC_PAIR_ODD_B64 -1
 #endif
-// Round 5 (the per-codeword fixed cost, DESIGN.md / profiles/r05_kbench/f32_fixed_cost.txt): the NEXT codeword's LLRs are brought into
-// LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no wait inside the iterations) during iteration 1 of the current decode,
-// instead of register loads issued behind the last iteration whose HBM latency the prologue then waits for.  f32 only (4-byte LLRs).
-// -1 = per type, 0 / 1 = force.
-#ifndef LDPC_PAIR_LLR_DMA
-#define LDPC_PAIR_LLR_DMA -1
-#endif
-// Round 5: flags, clamp vote and next-codeword word double-buffered by the codeword's parity, which makes the workgroup barrier behind the
-// epilogue unnecessary (without LLR_DMA only: the DMA's landing needs that barrier).  0 = off.
-#ifndef LDPC_PAIR_FLAG_SETS
-#define LDPC_PAIR_FLAG_SETS 0
-#endif
+
 // Wave priority over the six (check row, index) steps of the check phase; 3 before them.  A dozen
 // alternatives, also per quarter, measured 6.4-6.75 against 6.75 for this one.
 #ifndef LDPC_PRIO_ROWS_PAIR
 #define LDPC_PRIO_ROWS_PAIR {3, 3, 2, 2, 1, 0}
 #endif
-// Diagnostics (LDPC_KBENCH only, wrong or perturbed results): LDPC_DIAG_NOBARRIER, LDPC_DIAG_NOLDS,
-// LDPC_DIAG_NOMIN, LDPC_DIAG_NOSELFCORR, LDPC_DIAG_NOSIGN, LDPC_DIAG_NOPAR (leave an instruction group out: what does it
-// cost?), LDPC_DIAG_NOFETCH / NOPACK / NOVOTE / NOZERO (the same for the per-codeword prologue and epilogue), LDPC_DIAG_FIXED_ITERS (no early exit),
-// LDPC_DIAG_STAMPS (per-phase s_memtime sums).
