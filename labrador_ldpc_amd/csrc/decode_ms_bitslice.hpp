@@ -240,9 +240,6 @@ struct Geo {
     // Hard decisions in LDS instead of one register per block column (one ds_write per column and iteration; a read as well where a
     // wave holds several codewords, whose finished ones keep their decisions): the rate-1/2 codes, which that brings under the 168
     // registers of three waves per SIMD.
-#ifndef BS_TEST_NOFREEZE
-#define BS_TEST_NOFREEZE 0
-#endif
 #ifndef BS_HARD_LDS
 #define BS_HARD_LDS 1
 #endif
@@ -546,7 +543,7 @@ struct Decoder {
             });
             // hard decisions (decoder.rs:457-461): a wave that holds ONE codeword stops with it, so nothing is ever frozen there
             if constexpr (GEO::HARD_LDS) {
-                if constexpr (G == 1 || BS_TEST_NOFREEZE) b.lds_write32(hard_addr(c), va[7]);
+                if constexpr (G == 1) b.lds_write32(hard_addr(c), va[7]);
                 else b.lds_write32(hard_addr(c), B::select_lanes(frozen, b.lds_read32(hard_addr(c)), va[7]));   // (branch-free: an EXEC-masked
             } else if constexpr (G == 1) hard[c] = va[7];                                                        //  store would split the loop body)
             else hard[c] = B::select_lanes(frozen, hard[c], va[7]);
