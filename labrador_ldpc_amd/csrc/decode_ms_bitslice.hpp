@@ -97,6 +97,16 @@ static_assert(TT_XOR3 == 0x96 && TT_MAJ == 0xE8 && TT_MUX == 0xCA && TT_OR3 == 0
 
 constexpr int ilog2c(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
+// Bit planes of a message / marginal (two's complement).  8 = i8, what the library ships.  Everything below is written for PL planes: a
+// build with -DBS_PLANES=16 decodes with i16 saturation (the experiment behind DESIGN.md section 7: sign-extended i8 LLRs through the
+// i8 loader, checked against the i16 oracle in tests/test_bitslice_emu.py) -- twice the instructions and registers per edge.
+#ifndef BS_PLANES
+#define BS_PLANES 8
+#endif
+inline constexpr int PL = BS_PLANES, MG = PL - 1;          // planes of a value, of a magnitude
+inline constexpr int LLRP = 8;                             // planes of an LLR as the (i8) loader delivers it
+static_assert(PL == 8 || PL == 16);
+
 // ---- geometry of a code in the bit-sliced layout ----------------------------------------------------------------------
 // HALF = -1: one wave decodes a group of codewords alone.  HALF = 0 / 1: the wave is one of TWO that share a group, each owning a run of
 // block columns with all their edges (the "split" kernel of the rate-4/5 codes, decode_ms_bitslice_split.hpp): everything below that
@@ -219,7 +229,7 @@ struct Geo {
     }
     static constexpr PermOrder PERM_ORDER = perm_order();
     static constexpr int perm_after(int idx) { return PERM_ORDER.idx[(PERM_ORDER.pos[idx] + 1) % (2 * NX)]; }
-    static constexpr int LLR_WORDS = NTX_OWN * 8 * 64;             // words of LLR planes per wave
+    static constexpr int LLR_WORDS = NTX_OWN * LLRP * 64;          // words of LLR planes per wave
     // the rate-4/5 codes (39 edges: 218 planes of state before any temporary) exist only in the two-waves-per-group form
     static constexpr bool TWO_WAVES = P.n_blocks > 30;
     // Every state update of the rate-2/3 codes is pinned to its place in the program (Decoder::pin_update): without that the
@@ -244,7 +254,7 @@ struct Geo {
 #define BS_HARD_LDS 1
 #endif
     static constexpr bool HARD_LDS = !SPLIT && P.n_blocks <= 20 && BS_HARD_LDS;
-    static constexpr int ROW_NEW = 18 + ARG;                                   // planes of a row's running state
+    static constexpr int ROW_NEW = 2 * PL + 2 + ARG;                           // planes of a row's running state: two keys, sign, parity, arg-min
     // LDS of a wave: lane permutations of the exchanged blocks [NX][2 directions][64] as 16-bit entries (source lane address | rotate
     // amount << 8; constant for the kernel's lifetime), hard-decision words [NCOLS][64] -- which double as the staging slab (STAGE_BYTES)
     // of the LLR transposition (prologue only) --, LLR planes [NTX][8][64].
@@ -271,32 +281,48 @@ struct Arith {
     // + 1 rides on the carry-in sr).  INV: acc (-sat) w instead -- every bit of the addend inverted, which costs nothing: the truth
     // tables absorb the complements.  So one xr serves the variable side (add u) and the check side (subtract the same u) of an edge.
     template <bool INV>
-    static BS_FN void sat_add_x(V (&acc)[8], V sr, const V (&xr)[7])
+    static BS_FN void sat_add_x(V (&acc)[PL], V sr, const V (&xr)[MG])
     {
-        V sum[8];
+        V sum[PL];
         // stage 0: carry-in = the addend's sign; a ^ ~x ^ ~s = a ^ x ^ s
         sum[0] = op3<TT_XOR3>(acc[0], xr[0], sr);
         V c = INV ? op3<TT_MAJ_NBC>(acc[0], xr[0], sr) : op3<TT_MAJ>(acc[0], xr[0], sr);
-        sfor<1, 7>([&](auto K_) {
+        sfor<1, MG>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             sum[k] = INV ? op3<TT_XNOR3>(acc[k], xr[k], c) : op3<TT_XOR3>(acc[k], xr[k], c);
             c = INV ? op3<TT_MAJ_NB>(acc[k], xr[k], c) : op3<TT_MAJ>(acc[k], xr[k], c);
         });
-        sum[7] = INV ? op3<TT_XNOR3>(acc[7], sr, c) : op3<TT_XOR3>(acc[7], sr, c);       // the addend's bit 7 is its sign (sign extension)
-        const V ovf = INV ? op3<TT_OVF_NS>(acc[7], sr, sum[7]) : op3<TT_OVF>(acc[7], sr, sum[7]);
-        const V a7 = acc[7];
-        sfor<0, 7>([&](auto K_) {
+        sum[MG] = INV ? op3<TT_XNOR3>(acc[MG], sr, c) : op3<TT_XOR3>(acc[MG], sr, c);    // the addend's top bit is its sign (sign extension)
+        const V ovf = INV ? op3<TT_OVF_NS>(acc[MG], sr, sum[MG]) : op3<TT_OVF>(acc[MG], sr, sum[MG]);
+        const V a7 = acc[MG];
+        sfor<0, MG>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             acc[k] = op3<TT_SAT>(ovf, a7, sum[k]);
         });
-        acc[7] = op3<TT_MUX>(ovf, a7, sum[7]);
+        acc[MG] = op3<TT_MUX>(ovf, a7, sum[MG]);
     }
 
-    // a < b for 8-plane unsigned keys: the borrow out of a - b
-    static BS_FN V less_than(const V (&a)[8], const V (&b)[8])
+    // AND / OR of planes k[LO] .. k[HI - 1] (and of `seed`), three inputs per instruction
+    template <int LO, int HI> static BS_FN V and_planes(const V (&k)[PL])
+    {
+        V acc = k[LO];
+        sfor<0, (HI - LO - 1) / 2>([&](auto I_) { constexpr int i = LO + 1 + 2 * decltype(I_)::value; acc = op3<TT_AND3>(acc, k[i], k[i + 1]); });
+        if constexpr ((HI - LO - 1) % 2 == 1) acc = B::and_(acc, k[HI - 1]);
+        return acc;
+    }
+    template <int LO, int HI> static BS_FN V or_planes(V seed, const V (&k)[PL])
+    {
+        V acc = seed;
+        sfor<0, (HI - LO) / 2>([&](auto I_) { constexpr int i = LO + 2 * decltype(I_)::value; acc = op3<TT_OR3>(acc, k[i], k[i + 1]); });
+        if constexpr ((HI - LO) % 2 == 1) acc = B::or_(acc, k[HI - 1]);
+        return acc;
+    }
+
+    // a < b for PL-plane unsigned keys: the borrow out of a - b
+    static BS_FN V less_than(const V (&a)[PL], const V (&b)[PL])
     {
         V br = B::andn(b[0], a[0]);                           // ~a0 & b0
-        sfor<1, 8>([&](auto K_) {
+        sfor<1, PL>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             br = op3<TT_BORROW>(b[k], a[k], br);
         });
@@ -317,10 +343,10 @@ struct Decoder {
     // lane constants
     V lane, q, ll, cwbase;
     // old row state (read-only between a row's first and last edge of an iteration) and per-edge bits
-    V m1[NROWS][7], m2[NROWS][7], S[NROWS], arg[NROWS][ARG];
+    V m1[NROWS][MG], m2[NROWS][MG], S[NROWS], arg[NROWS][ARG];
     V sv[NB], nz[NB];
     // running state of the rows whose edges are being processed: keys (8 planes), sign product, parity, arg-min slot
-    V W1[NROWS][8], W2[NROWS][8], Sn[NROWS], Pn[NROWS], argn[NROWS][ARG];
+    V W1[NROWS][PL], W2[NROWS][PL], Sn[NROWS], Pn[NROWS], argn[NROWS][ARG];
     V hard[NCOLS];                      // (unused with Geo::HARD_LDS)
     V fail;                             // OR of the parities of the rows finished in this iteration (decoder.rs:453)
 
@@ -348,7 +374,7 @@ struct Decoder {
         sfor<0, NROWS>([&](auto R_) {
             constexpr int r = decltype(R_)::value;
             if constexpr (GEO::has_row(r)) {
-                sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
+                sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; m1[r][k] = B::c(0); m2[r][k] = B::c(0); });
                 S[r] = B::c(0);
                 sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
             }
@@ -396,7 +422,7 @@ struct Decoder {
 
     // u of edge E at CHECK alignment: sign su, magnitude mg[7]  (decoder.rs:391-405 from the compressed row state)
     template <int E>
-    BS_FN void edge_u(V &su, V (&mg)[7])
+    BS_FN void edge_u(V &su, V (&mg)[MG])
     {
         constexpr int r = GEO::P.blk[E].row, slot = GEO::slot_of(E);
         // (everything below depends on the OLD row state only, which exists from the top of the iteration: without the pins the
@@ -404,7 +430,7 @@ struct Decoder {
         sfor<0, ARG>([&](auto K_) { pin_use(arg[r][decltype(K_)::value]); });
         pin_use(S[r]);
         const V sel = is_arg<r, slot>();
-        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = op3<TT_MUX>(sel, m2[r][k], m1[r][k]); });
+        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = op3<TT_MUX>(sel, m2[r][k], m1[r][k]); });
         su = B::xor_(S[r], sv[E]);
     }
 
@@ -479,9 +505,9 @@ struct Decoder {
     // ---- a row's running state becomes its old state; minima back to magnitudes: (key + 1) >> 1 = (key >> 1) + (key & 1) ----
     template <int R> BS_FN void finish_row()
     {
-        auto to_mag = [&](const V (&key)[8], V (&mag)[7]) {
+        auto to_mag = [&](const V (&key)[PL], V (&mag)[MG]) {
             V c = key[0];
-            sfor<0, 7>([&](auto K_) {
+            sfor<0, MG>([&](auto K_) {
                 constexpr int k = decltype(K_)::value;
                 mag[k] = B::xor_(key[k + 1], c);
                 c = B::and_(key[k + 1], c);
@@ -493,7 +519,7 @@ struct Decoder {
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; arg[R][k] = argn[R][k]; });
         // (the magnitudes are formed HERE: left to the instruction selector, their last XORs sink to their first use in the next
         // iteration and keys and carries -- 24 planes instead of 14 -- stay live until then)
-        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_row(m1[R][k]); pin_row(m2[R][k]); });
+        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_row(m1[R][k]); pin_row(m2[R][k]); });
         fail = B::or_(fail, Pn[R]);                                                   // non-zero bits = unsatisfied checks (:453)
     }
 
@@ -513,75 +539,75 @@ struct Decoder {
             constexpr int c = GEO::COL_ORDER.col[decltype(I_)::value];
             B::fence();            // keep the compiler from hoisting the next column's loads over this one's arithmetic (register pressure)
             // ---- variable side: marginal of block column c (decoder.rs:382-383, :408) ----
-            V va[8];
+            V va[PL];
             if constexpr (c < NTX) {
                 const V at = B::shl(lane, 2);
-                sfor<0, 8>([&](auto K_) {
+                sfor<0, PL>([&](auto K_) {                       // (planes beyond the loader's: the sign plane again -- sign extension)
                     constexpr int k = decltype(K_)::value;
-                    va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)));
+                    va[k] = b.lds_read32(B::add(at, B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * LLRP + (k < LLRP ? k : LLRP - 1)) * 256)));
                 });
             } else {
-                sfor<0, 8>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
+                sfor<0, PL>([&](auto K_) { va[decltype(K_)::value] = B::c(0); });
             }
             // (u of a LOCAL edge -- an unshifted identity block: check and variable alignment coincide -- is the same expression here
             // and on the check side below, where the adder takes it inverted: the compiler forms it once)
             sfor<0, NB>([&](auto E_) {
                 constexpr int e = decltype(E_)::value;
                 if constexpr (GEO::P.blk[e].col == c) {
-                    V su, mg[7], x[7];
+                    V su, mg[MG], x[MG];
                     edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
                         const V addr = take_perm<GEO::exch_of(e) * 2 + 0>(b);
                         const V amt = B::shr(addr, 8);
-                        sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
+                        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
                         su = B::rotr(b.bperm(addr, su), amt);
                     }
-                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
                     A::template sat_add_x<false>(va, su, x);
                     B::fence();
                 }
             });
             // hard decisions (decoder.rs:457-461): a wave that holds ONE codeword stops with it, so nothing is ever frozen there
             if constexpr (GEO::HARD_LDS) {
-                if constexpr (G == 1) b.lds_write32(hard_addr(c), va[7]);
-                else b.lds_write32(hard_addr(c), B::select_lanes(frozen, b.lds_read32(hard_addr(c)), va[7]));   // (branch-free: an EXEC-masked
-            } else if constexpr (G == 1) hard[c] = va[7];                                                        //  store would split the loop body)
-            else hard[c] = B::select_lanes(frozen, hard[c], va[7]);
+                if constexpr (G == 1) b.lds_write32(hard_addr(c), va[MG]);
+                else b.lds_write32(hard_addr(c), B::select_lanes(frozen, b.lds_read32(hard_addr(c)), va[MG]));   // (branch-free: an EXEC-masked
+            } else if constexpr (G == 1) hard[c] = va[MG];                                                        //  store would split the loop body)
+            else hard[c] = B::select_lanes(frozen, hard[c], va[MG]);
             // ---- check side of the same edges (decoder.rs:419-447) ----
             sfor<0, NB>([&](auto E_) {
                 constexpr int e = decltype(E_)::value;
                 if constexpr (GEO::P.blk[e].col == c) {
                     constexpr int r = GEO::P.blk[e].row, slot = GEO::slot_of(e);
-                    V nv[8];
+                    V nv[PL];
                     if constexpr (!GEO::local(e)) {
                         const V addr = take_perm<GEO::exch_of(e) * 2 + 1>(b);
                         const V amt = B::shr(addr, 8);
-                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
+                        sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
                     } else {
-                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
+                        sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
                     }
-                    const V pbit = nv[7];                                            // hard bit of the marginal (:445-447)
-                    V su, mg[7], x[7];
+                    const V pbit = nv[MG];                                            // hard bit of the marginal (:445-447)
+                    V su, mg[MG], x[MG];
                     edge_u<e>(su, mg);
-                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
                     A::template sat_add_x<true>(nv, su, x);                          // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
-                    const V drop = op3<TT_DROP>(nz[e], sv[e], nv[7]);
+                    const V drop = op3<TT_DROP>(nz[e], sv[e], nv[MG]);
                     // v = drop ? 0 : nv is never formed: its sign, its key and "v != 0" follow from nv and drop directly.
                     // key of |v|: planes 1..7 = v ^ sign, plane 0 = sign -- except for -128, which is +127's key
-                    V key[8];
-                    sfor<0, 7>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = op3<TT_KEYBIT>(nv[k], nv[7], drop); });
-                    const V vs = B::andn(nv[7], drop);                               // sign of the new v
-                    const V all1 = B::and_(op3<TT_AND3>(key[1], key[2], key[3]), op3<TT_AND3>(key[4], key[5], key[6]));
-                    key[0] = op3<TT_KEY0>(vs, all1, key[7]);
+                    V key[PL];
+                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = op3<TT_KEYBIT>(nv[k], nv[MG], drop); });
+                    const V vs = B::andn(nv[MG], drop);                              // sign of the new v
+                    const V all1 = A::template and_planes<1, MG>(key);
+                    key[0] = op3<TT_KEY0>(vs, all1, key[MG]);
                     sv[e] = vs;
-                    nz[e] = op3<TT_OR3>(op3<TT_OR3>(key[1], key[2], key[3]), op3<TT_OR3>(key[4], key[5], key[6]), B::or_(key[7], vs));
+                    nz[e] = A::template or_planes<1, PL>(vs, key);
                     if constexpr (e == GEO::first_edge(r)) {
                         // the row's running state STARTS with this edge: every key is <= 254 = the key of maxval (decoder.rs:414-415), so
                         // after one insertion min1 = this key and min2 = 254 whatever the key -- no compare; the arg-min slot is this
                         // edge's (if the key IS 254 the reference's strict `<` would leave the slot alone, but then min1 = min2 and the
                         // slot selects between equal values)
-                        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = key[k]; W2[r][k] = B::c(k == 0 ? 0u : 0xFFFFFFFFu); });
+                        sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; W1[r][k] = key[k]; W2[r][k] = B::c(k == 0 ? 0u : 0xFFFFFFFFu); });
                         Pn[r] = pbit;
                         Sn[r] = vs;
                         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; argn[r][k] = B::c(((slot >> k) & 1) ? 0xFFFFFFFFu : 0u); });
@@ -591,7 +617,7 @@ struct Decoder {
                         // two running minima (:430-434)
                         const V lt1 = A::less_than(key, W1[r]);
                         const V lt2 = A::less_than(key, W2[r]);
-                        sfor<0, 8>([&](auto K_) {
+                        sfor<0, PL>([&](auto K_) {
                             constexpr int k = decltype(K_)::value;
                             const V t = op3<TT_MUX>(lt2, key[k], W2[r][k]);
                             W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], t);
@@ -606,7 +632,7 @@ struct Decoder {
                     // an iteration away (the new v's zero-ness, the row minima) at the END of the block, holding their operands -- seven
                     // key planes per edge -- in registers until then.  An opaque use pins each update where it is written (rate 2/3).
                     pin_update(sv[e]); pin_update(nz[e]); pin_update(Sn[r]); pin_update(Pn[r]);
-                    sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_update(W1[r][k]); pin_update(W2[r][k]); });
+                    sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_update(W1[r][k]); pin_update(W2[r][k]); });
                     sfor<0, ARG>([&](auto K_) { pin_update(argn[r][decltype(K_)::value]); });
                     if constexpr (e == GEO::last_edge(r) && !GEO::shared_row(r)) finish_row<r>();
                     B::fence();
@@ -752,7 +778,7 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
         load_column_planes<CODE>(b, d, llrs, c, group, batch, GEO::LDS_STAGE, X);
         sfor<0, 8>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * 8 + k) * 256)), X[k]);
+            b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (c * LLRP + k) * 256)), X[k]);
         });
     });
 

@@ -30,7 +30,7 @@ template <int CODE>
 struct SplitLayout {
     using G0 = Geo<CODE, 0>;
     using G1 = Geo<CODE, 1>;
-    static constexpr int XEXTRA = 18 + G0::ARG;                               // W1 8, W2 8, Sn, Pn, argn ARG; then the parity of the unshared rows
+    static constexpr int XEXTRA = 2 * PL + 2 + G0::ARG;                       // W1 PL, W2 PL, Sn, Pn, argn ARG; then the parity of the unshared rows
     static constexpr int XPLANES = XEXTRA + 1;
     static constexpr int XBYTES = XPLANES * 256;
     static_assert(XBYTES >= STAGE_BYTES, "the exchange buffer doubles as the staging slab of the LLR transposition");
@@ -85,7 +85,7 @@ struct SplitGroup {
                 load_column_planes<CODE>(b, d, llrs, c, group, batch, XO, X);      // (the staging slab is this wave's exchange buffer)
                 sfor<0, 8>([&](auto K_) {
                     constexpr int k = decltype(K_)::value;
-                    b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * 8 + k) * 256)), X[k]);
+                    b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::LDS_LLR + (GEO::llr_slot(c) * LLRP + k) * 256)), X[k]);
                 });
             }
         });
@@ -114,14 +114,14 @@ struct SplitGroup {
 
     template <int R> BS_FN void put_row(B &b, int base)
     {
-        sfor<0, 8>([&](auto K_) {
+        sfor<0, PL>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             b.lds_write32(xaddr(lane, base, k), d.W1[R][k]);
-            b.lds_write32(xaddr(lane, base, 8 + k), d.W2[R][k]);
+            b.lds_write32(xaddr(lane, base, PL + k), d.W2[R][k]);
         });
-        b.lds_write32(xaddr(lane, base, 16), d.Sn[R]);
-        b.lds_write32(xaddr(lane, base, 17), d.Pn[R]);
-        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(xaddr(lane, base, 18 + k), d.argn[R][k]); });
+        b.lds_write32(xaddr(lane, base, 2 * PL), d.Sn[R]);
+        b.lds_write32(xaddr(lane, base, 2 * PL + 1), d.Pn[R]);
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(xaddr(lane, base, 2 * PL + 2 + k), d.argn[R][k]); });
     }
 
     // ---- stage 2: the partial state of row PUB into this wave's buffer, with the parity of the rows only this wave has (the other
@@ -137,29 +137,29 @@ struct SplitGroup {
     BS_FN void stage_merge(B &b)
     {
         constexpr int R = MRG;
-        V o1[8], o2[8], oarg[ARG > 0 ? ARG : 1];
-        sfor<0, 8>([&](auto K_) {
+        V o1[PL], o2[PL], oarg[ARG > 0 ? ARG : 1];
+        sfor<0, PL>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             o1[k] = b.lds_read32(xaddr(lane, XT, k));
-            o2[k] = b.lds_read32(xaddr(lane, XT, 8 + k));
+            o2[k] = b.lds_read32(xaddr(lane, XT, PL + k));
         });
-        const V os = b.lds_read32(xaddr(lane, XT, 16)), op = b.lds_read32(xaddr(lane, XT, 17));
-        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; oarg[k] = b.lds_read32(xaddr(lane, XT, 18 + k)); });
+        const V os = b.lds_read32(xaddr(lane, XT, 2 * PL)), op = b.lds_read32(xaddr(lane, XT, 2 * PL + 1));
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; oarg[k] = b.lds_read32(xaddr(lane, XT, 2 * PL + 2 + k)); });
         extra_fail = b.lds_read32(xaddr(lane, XT, LAY::XEXTRA));
         // take the other's min1 where it is smaller -- wave 0's wins a tie, whichever wave merges
         V take;
         if constexpr (HALF == 0) take = A::less_than(o1, d.W1[R]);                  // other (wave 1) strictly smaller
         else take = B::not_(A::less_than(d.W1[R], o1));                             // mine (wave 1) not strictly smaller
-        V hi[8], lo[8];
+        V hi[PL], lo[PL];
         const V lt2 = A::less_than(o2, d.W2[R]);
-        sfor<0, 8>([&](auto K_) {
+        sfor<0, PL>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             hi[k] = op3<TT_MUX>(take, d.W1[R][k], o1[k]);                            // the larger of the two min1
             d.W1[R][k] = op3<TT_MUX>(take, o1[k], d.W1[R][k]);
             lo[k] = op3<TT_MUX>(lt2, o2[k], d.W2[R][k]);                             // the smaller of the two min2
         });
         const V lt3 = A::less_than(hi, lo);
-        sfor<0, 8>([&](auto K_) { constexpr int k = decltype(K_)::value; d.W2[R][k] = op3<TT_MUX>(lt3, hi[k], lo[k]); });
+        sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; d.W2[R][k] = op3<TT_MUX>(lt3, hi[k], lo[k]); });
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = op3<TT_MUX>(take, oarg[k], d.argn[R][k]); });
         d.Sn[R] = B::xor_(d.Sn[R], os);
         d.Pn[R] = B::xor_(d.Pn[R], op);
@@ -170,14 +170,14 @@ struct SplitGroup {
     BS_FN void stage_fetch(B &b)
     {
         constexpr int R = PUB;
-        sfor<0, 8>([&](auto K_) {
+        sfor<0, PL>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             d.W1[R][k] = b.lds_read32(xaddr(lane, XO, k));
-            d.W2[R][k] = b.lds_read32(xaddr(lane, XO, 8 + k));
+            d.W2[R][k] = b.lds_read32(xaddr(lane, XO, PL + k));
         });
-        d.Sn[R] = b.lds_read32(xaddr(lane, XO, 16));
-        d.Pn[R] = b.lds_read32(xaddr(lane, XO, 17));
-        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = b.lds_read32(xaddr(lane, XO, 18 + k)); });
+        d.Sn[R] = b.lds_read32(xaddr(lane, XO, 2 * PL));
+        d.Pn[R] = b.lds_read32(xaddr(lane, XO, 2 * PL + 1));
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = b.lds_read32(xaddr(lane, XO, 2 * PL + 2 + k)); });
     }
 
     // ---- stage 5: new state -> old state, the verdict of iteration `it` (the same in both waves) ----

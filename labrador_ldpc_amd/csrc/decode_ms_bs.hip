@@ -93,11 +93,13 @@ hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *out
                                       uint32_t maxiters, hipStream_t stream)
 {
     switch (code) {
+#if BS_PLANES == 8
         case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
         case TM1536: return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
-        case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
         case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
         case TM6144: return bs::launch<TM6144>(llrs, output, iters, success, batch, maxiters, stream);
+#endif                  // (a 16-plane experiment build, tools/bs_alt_build.sh -DBS_PLANES=16, carries the rate-1/2 codes only)
+        case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
         case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
         default: return hipErrorInvalidConfiguration;
     }

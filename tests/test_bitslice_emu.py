@@ -107,6 +107,40 @@ def test_emulated_two_wave_kernel_equals_the_oracle(emu, name):
         _same(emu, code, corner, maxiters, split=True)
 
 
+@pytest.mark.parametrize("name", ["TM2048", "TM8192"])
+def test_sixteen_plane_build_equals_the_i16_oracle(name):
+    """Round 4's review, item 4 (i): the plane count is a parameter of the kernel text (BS_PLANES, decode_ms_bitslice.hpp).  Built with
+    16 planes the same text decodes with i16 saturation: sign-extended i8 LLRs through the i8 loader must give exactly what the oracle's
+    decode_ms::<i16> (src/decoder.rs:51-59) gives on those values as i16 -- including frames whose marginals leave the i8 range (scale 30:
+    sums of six +-127 messages), where the 8-plane build saturates and the 16-plane one must not.  (The GPU rate of this build:
+    profiles/r05_kbench/bs_i16_tc.txt.)"""
+    code = oracle.CODES.index(name)
+    lib = os.path.join(ROOT, "build", f"libbitslice_emu16_{name}.so")
+    src = [os.path.join(ROOT, "tests", "c", "bitslice_emu.cpp")] + [os.path.join(ROOT, "labrador_ldpc_amd", "csrc", f) for f in
+           ("decode_ms_bitslice.hpp", "decode_ms_bitslice_split.hpp", "decode_bf_bitslice.hpp", "codes.hpp")]
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in src):
+        subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", f"-DEMU_CODE={name}", "-DBS_PLANES=16",
+                               "-I" + os.path.join(ROOT, "labrador_ldpc_amd", "csrc"), src[0], "-o", lib])
+    L = ctypes.CDLL(lib)
+    L.bs_emu_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+    rng = np.random.default_rng(1600 + code)
+    differs_from_i8 = False
+    for ebn0, scale, lim, frames in ((2.5, 8.0, 31, 5), (1.0, 30.0, 127, 3), (4.5, 30.0, 127, 4), (3.0, 60.0, 127, 3)):
+        llrs, _ = oracle.awgn_llrs(code, rng, frames, ebn0, np.int8, scale=scale, lim=lim)
+        if scale > 8:
+            llrs[:, ::11] = -128                                    # |-128| = 128 in i16: no saturating abs there
+        for maxiters in (25, 3, 0):
+            B = llrs.shape[0]
+            out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
+            it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
+            assert L.bs_emu_decode(np.ascontiguousarray(llrs).ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
+            oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs.astype(np.int16), maxiters)
+            assert (out == oc).all() and (it == ic).all() and (ok == kc).all(), (name, ebn0, scale, maxiters)
+            o8, i8_, k8, _ = oracle.decode_ms_batch(code, llrs, maxiters)
+            differs_from_i8 = differs_from_i8 or bool((o8 != oc).any() or (i8_ != ic).any())
+    assert differs_from_i8                                           # (the inputs do exercise the difference between the two types)
+
+
 @pytest.mark.parametrize("name", ["TM1280", "TM2048", "TM6144"])
 def test_emulated_kernel_on_corner_inputs(emu, name):
     code = oracle.CODES.index(name)
