@@ -229,6 +229,67 @@ struct Geo {
     }
     static constexpr PermOrder PERM_ORDER = perm_order();
     static constexpr int perm_after(int idx) { return PERM_ORDER.idx[(PERM_ORDER.pos[idx] + 1) % (2 * NX)]; }
+    // The lane permutations of an iteration as a list of JOBS in that same order (job j uses table entry PERM_ORDER.idx[j]): side 0 =
+    // an exchanged edge's u from check to variable alignment, side 1 = its block column's marginal the way back.  A job's eight
+    // ds_bpermute can be issued one job AHEAD of their use (PIPE) when their source exists by then: u depends on the OLD row state
+    // only (any time), the marginal is complete once the column's variable side is (so only behind another side-1 job of the column).
+    struct Jobs { int edge[2 * NB + 1]; int side[2 * NB + 1]; int n; };
+    static constexpr Jobs jobs()
+    {
+        Jobs o{};
+        for (int i = 0; i < COL_ORDER.n; ++i)
+            for (int side = 0; side < 2; ++side)
+                for (int e = 0; e < NB; ++e)
+                    if (P.blk[e].col == COL_ORDER.col[i] && owns(e) && !local(e)) { o.edge[o.n] = e; o.side[o.n] = side; ++o.n; }
+        return o;
+    }
+    static constexpr Jobs JOBS = jobs();
+    static constexpr int job_of(int e, int side) { for (int j = 0; j < JOBS.n; ++j) if (JOBS.edge[j] == e && JOBS.side[j] == side) return j; return -1; }
+#ifndef BS_PIPE
+#define BS_PIPE 3
+#endif
+    // bit 0: the two-wave kernels, bit 1: rate 2/3, bit 2: rate 1/2 (which has no registers for it: 21-23 spilled values, -3 %).
+    // What it buys is not hidden latency -- the SIMD's other wave hid that already -- but ONE s_waitcnt per job instead of one per
+    // plane: a job's results have long arrived when they are collected (profiles/r05_kbench/permute_pipeline.txt: +1.2 ... +1.9 %).
+    // M = 128 (TM1280): a quarter is ONE lane and a codeword one quad of lanes, so the lane permutation of a pi_k block is a rotation of
+    // the quad by theta_k -- a DPP quad_perm on a v_mov_b32 (no LDS, no latency; nothing at all for theta_k = 0) instead of a
+    // ds_bpermute_b32, which at two waves per SIMD costs the SIMD ~4.4 x a VALU instruction (profiles/r04_kbench/sdwa_rate.txt).
+#ifndef BS_QUAD
+#define BS_QUAD 1
+#endif
+    static constexpr bool QUAD = W == 4 && BS_QUAD;
+    static constexpr int quad_ctrl(int e, int side)
+    {
+        const int th = theta_of(P.blk[e].val);
+        int c = 0;
+        for (int i = 0; i < 4; ++i) c |= ((side == 0 ? i - th : i + th) & 3) << (2 * i);
+        return c;
+    }
+    static constexpr bool PIPE = ((SPLIT ? 1 : P.n_blocks > 20 ? 2 : 4) & BS_PIPE) != 0 && !QUAD;
+    // job j + 1 is issued before job j's results are used
+    static constexpr bool issues_next(int j)
+    {
+        if (!PIPE || j < 0 || j + 1 >= JOBS.n) return false;
+        return JOBS.side[j + 1] == 0 || (JOBS.side[j] == 1 && P.blk[JOBS.edge[j]].col == P.blk[JOBS.edge[j + 1]].col);
+    }
+    static constexpr bool issued_early(int j) { return j > 0 && issues_next(j - 1); }
+    // An exchanged edge's u is needed twice, at check alignment: permuted into the marginal (variable side) and subtracted from the
+    // permuted marginal (check side).  For the first KEEP exchanged edges of a block column the (sign, magnitude ^ sign) planes formed
+    // for the variable side are KEPT for the check side instead of formed again (the seven XORs and whatever of the row-state multiplexer
+    // the compiler did not carry over by itself; the registers exist: the kept planes die at the start of the check side, before its peak).
+    // Measured +0.4 ... +2 % on every code (profiles/r05_kbench/permute_pipeline.txt).
+#ifndef BS_KEEP_SPLIT
+#define BS_KEEP_SPLIT 3
+#endif
+#ifndef BS_KEEP_R23
+#define BS_KEEP_R23 3
+#endif
+#ifndef BS_KEEP_R12
+#define BS_KEEP_R12 3
+#endif
+    static constexpr int KEEP = SPLIT ? BS_KEEP_SPLIT : P.n_blocks > 20 ? BS_KEEP_R23 : BS_KEEP_R12;
+    static constexpr int keep_rank(int e) { int s = 0; for (int i = 0; i < e; ++i) s += (owns(i) && !local(i) && P.blk[i].col == P.blk[e].col) ? 1 : 0; return s; }
+    static constexpr bool kept(int e) { return owns(e) && !local(e) && keep_rank(e) < KEEP; }
     static constexpr int LLR_WORDS = NTX_OWN * LLRP * 64;          // words of LLR planes per wave
     // the rate-4/5 codes (39 edges: 218 planes of state before any temporary) exist only in the two-waves-per-group form
     static constexpr bool TWO_WAVES = P.n_blocks > 30;
@@ -484,6 +545,44 @@ struct Decoder {
         pnext = perm_entry<GEO::perm_after(IDX)>(b);
         return a;
     }
+    // ---- a permutation job's eight ds_bpermute, issued (possibly a job ahead: Geo::PIPE) and collected ----
+    V pend[PL], pamt;
+    V kx[GEO::KEEP > 0 ? GEO::KEEP : 1][MG], ksu[GEO::KEEP > 0 ? GEO::KEEP : 1];
+    template <int J> BS_FN void issue_job(B &b, const V (&va)[PL])
+    {
+        constexpr int e = GEO::JOBS.edge[J], side = GEO::JOBS.side[J];
+        const V addr = take_perm<GEO::exch_of(e) * 2 + side>(b);
+        pamt = B::shr(addr, 8);
+        auto move = [&](V x) {
+            if constexpr (GEO::QUAD) return B::template quad_perm<GEO::quad_ctrl(e, side)>(x);
+            else return b.bperm(addr, x);
+        };
+        if constexpr (side == 0) {
+            V su, mg[MG];
+            edge_u<e>(su, mg);
+            if constexpr (GEO::kept(e)) {
+                constexpr int kr = GEO::keep_rank(e);
+                sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; kx[kr][k] = B::xor_(mg[k], su); pend[k] = move(kx[kr][k]); });
+                ksu[kr] = su;
+            } else {
+                sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; pend[k] = move(mg[k]); });
+            }
+            pend[MG] = move(su);
+        } else {
+            sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; pend[k] = move(va[k]); });
+        }
+    }
+    // the results of job J, rotated into place; then the NEXT job's permutes go out, in front of this job's arithmetic
+    template <int J> BS_FN void collect_job(B &b, V (&got)[PL], const V (&va)[PL])
+    {
+        if constexpr (!GEO::issued_early(J)) issue_job<J>(b, va);
+        const V amt = pamt;
+        if constexpr (GEO::PIPE) { B::fence(); B::lds_wait(); B::fence(); }         // (one s_waitcnt lgkmcnt(0) for the eight results)
+        sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; got[k] = B::rotr(pend[k], amt); });
+        if constexpr (GEO::PIPE) B::fence();
+        if constexpr (GEO::issues_next(J)) { issue_job<J + 1>(b, va); B::fence(); }
+    }
+
     template <int IDX> BS_FN void put_perm_entry(B &b, V w) const { b.lds_write16(B::add(B::shl(lane, 1), B::c(GEO::LDS_PERM + IDX * 128)), w); }
 
     // The permutations depend on the lane only: computed once per kernel into LDS.  ds_bpermute_b32 reads bits 7:2 of its address
@@ -555,14 +654,16 @@ struct Decoder {
                 constexpr int e = decltype(E_)::value;
                 if constexpr (GEO::P.blk[e].col == c) {
                     V su, mg[MG], x[MG];
-                    edge_u<e>(su, mg);
                     if constexpr (!GEO::local(e)) {
-                        const V addr = take_perm<GEO::exch_of(e) * 2 + 0>(b);
-                        const V amt = B::shr(addr, 8);
-                        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = B::rotr(b.bperm(addr, mg[k]), amt); });
-                        su = B::rotr(b.bperm(addr, su), amt);
+                        V got[PL];
+                        collect_job<GEO::job_of(e, 0)>(b, got, va);
+                        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; mg[k] = got[k]; });
+                        su = got[MG];
+                    } else {
+                        edge_u<e>(su, mg);
                     }
-                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    if constexpr (GEO::kept(e)) sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = mg[k]; });      // (permuted as x)
+                    else sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
                     A::template sat_add_x<false>(va, su, x);
                     B::fence();
                 }
@@ -580,16 +681,20 @@ struct Decoder {
                     constexpr int r = GEO::P.blk[e].row, slot = GEO::slot_of(e);
                     V nv[PL];
                     if constexpr (!GEO::local(e)) {
-                        const V addr = take_perm<GEO::exch_of(e) * 2 + 1>(b);
-                        const V amt = B::shr(addr, 8);
-                        sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = B::rotr(b.bperm(addr, va[k]), amt); });
+                        collect_job<GEO::job_of(e, 1)>(b, nv, va);
                     } else {
                         sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; nv[k] = va[k]; });
                     }
                     const V pbit = nv[MG];                                            // hard bit of the marginal (:445-447)
                     V su, mg[MG], x[MG];
-                    edge_u<e>(su, mg);
-                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    if constexpr (GEO::kept(e)) {
+                        constexpr int kr = GEO::keep_rank(e);
+                        su = ksu[kr];
+                        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = kx[kr][k]; });
+                    } else {
+                        edge_u<e>(su, mg);
+                        sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
+                    }
                     A::template sat_add_x<true>(nv, su, x);                          // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
                     const V drop = op3<TT_DROP>(nz[e], sv[e], nv[MG]);

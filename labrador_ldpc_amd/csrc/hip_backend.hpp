@@ -17,6 +17,7 @@ struct HipBackend {
     char *lds;
 
     static BS_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
+    static BS_FN void lds_wait() { __builtin_amdgcn_s_waitcnt(0xC07F); }   // s_waitcnt lgkmcnt(0): every LDS result of this wave is in its register
     static BS_FN void pin(V &x) { asm volatile("" : "+v"(x)); }          // the value exists in a register HERE (see the iteration)
     static BS_FN V c(uint32_t x) { return x; }
     BS_FN V lane() const { return threadIdx.x & 63u; }
@@ -38,6 +39,12 @@ struct HipBackend {
     static BS_FN V rotr(V x, V amt) { return __builtin_amdgcn_alignbit(x, x, amt); }
     static BS_FN V less_u(V a, V b) { return a < b ? 0xFFFFFFFFu : 0u; }
     static BS_FN V eq(V a, V b) { return a == b ? 0xFFFFFFFFu : 0u; }
+    // lane i takes x of lane (i & ~3) | bits 2i+1:2i of CTRL: v_mov_b32_dpp quad_perm (the identity costs nothing)
+    template <int CTRL> static BS_FN V quad_perm(V x)
+    {
+        if constexpr (CTRL == 0xE4) return x;
+        else return (V)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xF, 0xF, true);
+    }
     BS_FN V bperm(V addr, V x) const { return (V)__builtin_amdgcn_ds_bpermute((int)addr, (int)x); }
     BS_FN V lds_read32(V addr) const { return *reinterpret_cast<const uint32_t *>(lds + addr); }
     BS_FN void lds_write32(V addr, V v) { *reinterpret_cast<uint32_t *>(lds + addr) = v; }
@@ -50,11 +57,14 @@ struct HipBackend {
         return pred ? *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off) : 0u;
     }
     static BS_FN V gload32(const void *p, V off) { return *reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + off); }
-    // 16 bytes per lane at a 4-byte-aligned address (global_load_dwordx4 takes any dword alignment)
+    // 16 bytes per lane at a 4-byte-aligned address (global_load_dwordx4 takes any dword alignment).  The LLRs are read once and the
+    // outputs written once: both streams are non-temporal, so that they do not push the few values the rate-1/2 kernels keep in scratch
+    // (11-14 spilled registers per wave, re-used every iteration) out of the L2 -- with default-policy loads 28 % more bytes were
+    // fetched and 2.9 x the output bytes written at the HBM boundary (TM8192 i8; profiles/r05_kbench/spill_leak.txt).
     static BS_FN void gload128(const void *p, V off, V (&w)[4])
     {
         typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4)));
-        const u4 v = *reinterpret_cast<const u4 *>(static_cast<const char *>(p) + off);
+        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(static_cast<const char *>(p) + off));
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     }
     BS_FN void lds_write128(V addr, const V (&w)[4])                    // 16-byte aligned
@@ -62,7 +72,7 @@ struct HipBackend {
         typedef uint32_t u4a __attribute__((ext_vector_type(4)));
         *reinterpret_cast<u4a *>(lds + addr) = u4a{w[0], w[1], w[2], w[3]};
     }
-    static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off) = v; }
+    static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off)); }
     static BS_FN void gstore8(void *p, V off, V v, V pred) { if (pred) static_cast<uint8_t *>(p)[off] = (uint8_t)v; }
     // lane-wise select by a 64-bit lane mask: one v_cndmask_b32 with the mask in an SGPR pair, no plane of the mask in a register
     static BS_FN V select_lanes(uint64_t m, V a, V b)

@@ -38,6 +38,7 @@ struct EmuBackend {
     template <class F> static V map2(const V &a, const V &b, F f) { V r; for (int i = 0; i < 64; ++i) r.l[i] = f(a.l[i], b.l[i]); return r; }
 
     static void fence() {}
+    static void lds_wait() {}
     static void pin(V &) {}
     static V c(uint32_t x) { V r; for (auto &e : r.l) e = x; return r; }
     V lane() const { V r; for (int i = 0; i < 64; ++i) r.l[i] = (uint32_t)i; return r; }
@@ -69,6 +70,7 @@ struct EmuBackend {
     static V rotr(const V &x, const V &amt) { return map2(x, amt, [](uint32_t v, uint32_t a) { a &= 31; return a ? (v >> a) | (v << (32 - a)) : v; }); }
     static V less_u(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x < y ? 0xFFFFFFFFu : 0u; }); }
     static V eq(const V &a, const V &b) { return map2(a, b, [](uint32_t x, uint32_t y) { return x == y ? 0xFFFFFFFFu : 0u; }); }
+    template <int CTRL> static V quad_perm(const V &x) { V r; for (int i = 0; i < 64; ++i) r.l[i] = x.l[(i & ~3) | ((CTRL >> (2 * (i & 3))) & 3)]; return r; }
     V bperm(const V &addr, const V &x) const { V r; for (int i = 0; i < 64; ++i) r.l[i] = x.l[(addr.l[i] >> 2) & 63]; return r; }
     V lds_read32(const V &addr) const { V r; for (int i = 0; i < 64; ++i) std::memcpy(&r.l[i], &lds_().at(addr.l[i]), 4), (void)lds_().at(addr.l[i] + 3); return r; }
     void lds_write32(const V &addr, const V &v) { for (int i = 0; i < 64; ++i) { (void)lds_().at(addr.l[i] + 3); std::memcpy(&lds_().at(addr.l[i]), &v.l[i], 4); } }
