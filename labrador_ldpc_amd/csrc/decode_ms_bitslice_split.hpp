@@ -13,8 +13,8 @@
 // wave 1's).  Each wave accumulates the row state over ITS edges.  Once per iteration wave 0 publishes its partial state of row 1 and
 // wave 1 of row 2 (a 24-plane LDS buffer per wave); after a barrier each wave merges the row the OTHER published into its own partial
 // state of that row (the two smallest keys of a union are min(a1, b1) and min(max(a1, b1), min(a2, b2)); signs and parities XOR; the
-// arg-min slot follows the smaller min1, wave 0's on a tie) and writes the merged row back into the other's buffer; after a second
-// barrier each wave fetches the merged state of the row it published.  Both waves then hold the same state.  One merge per wave and
+// arg-min slot follows the smaller min1, wave 0's on a tie), finishes the row (minima back to magnitudes: the row's new OLD state) and
+// writes that into the other's buffer; after a second barrier each wave fetches the finished state of the row it published.  Both waves then hold the same state.  One merge per wave and
 // two workgroup barriers per iteration (two waves with balanced work: they arrive together).
 //
 // The stages are separate member functions so that tests/c/bitslice_emu.cpp can run the two halves of a group alternately on the CPU.
@@ -129,8 +129,10 @@ struct SplitGroup {
     BS_FN void stage_publish(B &b)
     {
         put_row<PUB>(b, XO);
-        b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), d.fail);
+        if constexpr (has_unshared(HALF)) b.lds_write32(xaddr(lane, XO, LAY::XEXTRA), d.fail);
     }
+    // a half has block rows of its own (row 0 of the rate-4/5 codes is all wave 1's): their parity goes along for the other's verdict
+    static constexpr bool has_unshared(int h) { for (int r = 0; r < NROWS; ++r) if (GEO::row_in_half(r, h) && !GEO::row_in_half(r, 1 - h)) return true; return false; }
 
     // ---- stage 3: the other wave's partial state of row MRG (in ITS buffer) merged into this wave's; the result goes back into that
     // buffer, where its owner fetches it ----
@@ -145,7 +147,7 @@ struct SplitGroup {
         });
         const V os = b.lds_read32(xaddr(lane, XT, 2 * PL)), op = b.lds_read32(xaddr(lane, XT, 2 * PL + 1));
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; oarg[k] = b.lds_read32(xaddr(lane, XT, 2 * PL + 2 + k)); });
-        extra_fail = b.lds_read32(xaddr(lane, XT, LAY::XEXTRA));
+        if constexpr (has_unshared(1 - HALF)) extra_fail = b.lds_read32(xaddr(lane, XT, LAY::XEXTRA));
         // take the other's min1 where it is smaller -- wave 0's wins a tie, whichever wave merges
         V take;
         if constexpr (HALF == 0) take = A::less_than(o1, d.W1[R]);                  // other (wave 1) strictly smaller
@@ -163,27 +165,37 @@ struct SplitGroup {
         sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = op3<TT_MUX>(take, oarg[k], d.argn[R][k]); });
         d.Sn[R] = B::xor_(d.Sn[R], os);
         d.Pn[R] = B::xor_(d.Pn[R], op);
-        put_row<R>(b, XT);
+        // the merged row is FINISHED here (minima back to magnitudes, new state -> old state) and handed back in that form: the
+        // other wave takes 2 * 7 + 2 + ARG planes as they are instead of 2 * 8 + 2 + ARG and the conversion once more
+        d.template finish_row<R>();
+        sfor<0, MG>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            b.lds_write32(xaddr(lane, XT, k), d.m1[R][k]);
+            b.lds_write32(xaddr(lane, XT, MG + k), d.m2[R][k]);
+        });
+        b.lds_write32(xaddr(lane, XT, 2 * MG), d.S[R]);
+        b.lds_write32(xaddr(lane, XT, 2 * MG + 1), d.Pn[R]);
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; b.lds_write32(xaddr(lane, XT, 2 * MG + 2 + k), d.arg[R][k]); });
     }
 
-    // ---- stage 4: the merged state of row PUB, which the other wave left in this wave's buffer ----
+    // ---- stage 4: the merged and finished state of row PUB, which the other wave left in this wave's buffer ----
     BS_FN void stage_fetch(B &b)
     {
         constexpr int R = PUB;
-        sfor<0, PL>([&](auto K_) {
+        sfor<0, MG>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
-            d.W1[R][k] = b.lds_read32(xaddr(lane, XO, k));
-            d.W2[R][k] = b.lds_read32(xaddr(lane, XO, PL + k));
+            d.m1[R][k] = b.lds_read32(xaddr(lane, XO, k));
+            d.m2[R][k] = b.lds_read32(xaddr(lane, XO, MG + k));
         });
-        d.Sn[R] = b.lds_read32(xaddr(lane, XO, 2 * PL));
-        d.Pn[R] = b.lds_read32(xaddr(lane, XO, 2 * PL + 1));
-        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.argn[R][k] = b.lds_read32(xaddr(lane, XO, 2 * PL + 2 + k)); });
+        d.S[R] = b.lds_read32(xaddr(lane, XO, 2 * MG));
+        d.fail = B::or_(d.fail, b.lds_read32(xaddr(lane, XO, 2 * MG + 1)));              // its parity: unsatisfied checks (:453)
+        sfor<0, ARG>([&](auto K_) { constexpr int k = decltype(K_)::value; d.arg[R][k] = b.lds_read32(xaddr(lane, XO, 2 * MG + 2 + k)); });
     }
 
-    // ---- stage 5: new state -> old state, the verdict of iteration `it` (the same in both waves) ----
+    // ---- stage 5: the verdict of iteration `it` (the same in both waves) ----
     BS_FN void stage_finish(B &b, uint32_t it)
     {
-        const V fail = B::or_(d.finish_iteration(b), extra_fail);
+        const V fail = B::or_(d.fail, extra_fail);
         const uint64_t unsat_lanes = b.ballot(fail);
         sfor<0, G>([&](auto G_) {
             constexpr int g = decltype(G_)::value;
