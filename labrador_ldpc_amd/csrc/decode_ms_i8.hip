@@ -24,10 +24,10 @@ hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *out
                                       uint32_t maxiters, hipStream_t stream);
 constexpr int VARIANT_BITSLICE = 64;
 // groups of 64 / (M/32) codewords from which the bit-sliced kernel is faster per call (tools/bs_crossover.py,
-// profiles/r05_kbench/bs_crossover.txt: TM8192 crosses at 1024 groups, TM6144 and TM5120 at 768, the others at 2048)
+// profiles/r05_kbench/bs_crossover.txt: TM8192 and TM1280 cross at 1024 groups, TM6144 and TM5120 at 768, TM2048 and TM1536 at 2048)
 constexpr size_t bitslice_min_batch(int code)
 {
-    constexpr size_t groups[NUM_CODES] = {0, 0, 0, 2048, 2048, 2048, 768, 768, 1024};
+    constexpr size_t groups[NUM_CODES] = {0, 0, 0, 1024, 2048, 2048, 768, 768, 1024};
     return code >= TM1280 && code <= TM8192 ? groups[code] * (size_t)(64 / (CODES[code].m / 32)) : ~(size_t)0;
 }
 // its loads and stores are dwords: both buffers 4-byte aligned

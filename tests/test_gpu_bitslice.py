@@ -75,7 +75,7 @@ def test_bitsliced_kernel_equals_the_default_i8_kernel_on_a_large_batch(code):
     old = 32 if code == LDPCCode.TM8192 else 1                  # the f32-pipe kernels by their explicit variant
     a = code.decode_ms_batch(llrs, 25, variant=old)
     b = code.decode_ms_batch(llrs, 25, variant=BS)
-    c = code.decode_ms_batch(llrs, 25)                          # the default: bit-sliced from 1024 ... 32768 groups up, by code
+    c = code.decode_ms_batch(llrs, 25)                          # the default: bit-sliced from 768 ... 2048 groups up, by code
     torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(a, c))
     assert 0.5 < float(a[2].float().mean()) <= 1.0
