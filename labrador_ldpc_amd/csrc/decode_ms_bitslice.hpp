@@ -930,7 +930,10 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     sfor<0, NCOLS>([&](auto C_) {
         constexpr int c = decltype(C_)::value;
         const V out = pack_hard_column<CODE>(b, d, GEO::LDS_HARD + GEO::col_slot(c) * 256);
-        b.gstore32(output, B::add(B::mul_u(cw2, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw2, 2))), out, valid2);
+        // (the kernels that keep spilled values in scratch stream their output past the L2 as well: default-policy stores allocate
+        // lines there and cost TM8192 4 % and TM2048 3 %; profiles/r05_kbench/spill_leak.txt)
+        if constexpr (GEO::HARD_LDS) b.gstore32_stream(output, B::add(B::mul_u(cw2, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw2, 2))), out, valid2);
+        else b.gstore32(output, B::add(B::mul_u(cw2, (uint32_t)GEO::OUT_LEN), B::add(B::c((uint32_t)c * (M / 8)), B::shl(lw2, 2))), out, valid2);
     });
     const V first = B::and_(valid2, B::eq(lw2, B::c(0)));
     b.gstore32(iters, B::shl(cw2, 2), iters_v, first);

@@ -60,9 +60,9 @@ struct HipBackend {
     // 16 bytes per lane at a 4-byte-aligned address (global_load_dwordx4 takes any dword alignment).  The LLRs are read once: a
     // non-temporal stream, so that they do not push the few values the rate-1/2 kernels keep in scratch (11-14 spilled registers per
     // wave, re-used every iteration) out of the L2 -- with default-policy loads 28 % more bytes were fetched and 2.9 x the output bytes
-    // written at the HBM boundary (TM8192 i8; profiles/r05_kbench/spill_leak.txt).  The output stores keep the default policy: a
-    // codeword's 4 * W bytes per block column are a partial line where W < 32, which the L2 merges and a non-temporal store does not
-    // (TM5120: 1.5 x the output bytes).
+    // written at the HBM boundary (TM8192 i8; profiles/r05_kbench/spill_leak.txt).  Output stores: non-temporal too in the kernels that spill
+    // (gstore32_stream: the rate-1/2 codes), default policy in the others: a codeword's 4 * W bytes per block column are a partial line
+    // where W < 32, which the L2 merges and a non-temporal store does not (TM5120: 1.5 x the output bytes for no gain in rate).
     static BS_FN void gload128(const void *p, V off, V (&w)[4])
     {
         typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -75,6 +75,7 @@ struct HipBackend {
         *reinterpret_cast<u4a *>(lds + addr) = u4a{w[0], w[1], w[2], w[3]};
     }
     static BS_FN void gstore32(void *p, V off, V v, V pred) { if (pred) *reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off) = v; }
+    static BS_FN void gstore32_stream(void *p, V off, V v, V pred) { if (pred) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(static_cast<char *>(p) + off)); }
     static BS_FN void gstore8(void *p, V off, V v, V pred) { if (pred) static_cast<uint8_t *>(p)[off] = (uint8_t)v; }
     // lane-wise select by a 64-bit lane mask: one v_cndmask_b32 with the mask in an SGPR pair, no plane of the mask in a register
     static BS_FN V select_lanes(uint64_t m, V a, V b)

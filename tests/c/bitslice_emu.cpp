@@ -94,6 +94,7 @@ struct EmuBackend {
         }
     }
     static void gstore32(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) std::memcpy((char *)p + off.l[i], &v.l[i], 4); }
+    static void gstore32_stream(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) std::memcpy((char *)p + off.l[i], &v.l[i], 4); }
     static void gstore8(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) ((uint8_t *)p)[off.l[i]] = (uint8_t)v.l[i]; }
     static V select_lanes(uint64_t m, const V &a, const V &b) { V r; for (int i = 0; i < 64; ++i) r.l[i] = ((m >> i) & 1) ? a.l[i] : b.l[i]; return r; }
     static uint64_t ballot(const V &x) { uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(x.l[i] != 0) << i; return m; }
