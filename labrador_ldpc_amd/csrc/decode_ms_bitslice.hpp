@@ -323,10 +323,23 @@ struct Geo {
     // (dead by then) and the staging slab is the wave's exchange buffer, which lies behind both private areas (SplitLayout).
     static constexpr int LDS_PERM = 0, LDS_PERM_END = LDS_PERM + NX * 2 * 64 * 2;
     static constexpr int HARD_BYTES = NCOLS_OWN * 256 > 2304 ? NCOLS_OWN * 256 : 2304;             // (>= STAGE_BYTES, a multiple of 256)
+    // Rate 1/2 (three waves per SIMD, 168 registers): the "v != 0" plane of the first NZ_LDS edges lives in LDS -- read once and written
+    // once per iteration, at the edge's check side -- in the part of the staging slab that the hard-decision words leave free during
+    // the iterations: four planes the register allocator would otherwise keep in scratch (spilled values 11/14 -> 8/10; TM8192 i8
+    // +2...+3.5 %, TM2048 +1.5 %).  More than the slab holds costs a wave per CU: 6 planes -3 % (profiles/r05_kbench/spill_leak.txt).
+#ifndef BS_NZ_LDS
+#define BS_NZ_LDS 4
+#endif
+    static constexpr int NZ_LDS = HARD_LDS ? BS_NZ_LDS : 0;
+    static constexpr int NZ_IN_SLAB = (HARD_BYTES - NCOLS_OWN * 256) / 256 < NZ_LDS ? (HARD_BYTES - NCOLS_OWN * 256) / 256 : NZ_LDS;
+    static constexpr int nz_slot(int e) { int s = 0; for (int i = 0; i < e; ++i) s += owns(i) ? 1 : 0; return s; }       // ordinal among the owned edges
+    static constexpr bool nz_in_lds(int e) { return owns(e) && nz_slot(e) < NZ_LDS; }
     static constexpr int LDS_HARD = LDS_PERM_END, LDS_STAGE = LDS_HARD,
                          LDS_LLR = SPLIT ? LDS_PERM_END : LDS_HARD + HARD_BYTES,
                          LDS_PRIVATE = LDS_LLR + LLR_WORDS * 4,
-                         LDS_BYTES = LDS_PRIVATE;
+                         LDS_NZ_TAIL = LDS_PRIVATE,
+                         LDS_BYTES = LDS_PRIVATE + (NZ_LDS - NZ_IN_SLAB) * 256;
+    static constexpr int nz_addr(int e) { return nz_slot(e) < NZ_IN_SLAB ? LDS_HARD + (NCOLS_OWN + nz_slot(e)) * 256 : LDS_NZ_TAIL + (nz_slot(e) - NZ_IN_SLAB) * 256; }
     static_assert(!SPLIT || NCOLS_OWN * 256 <= LLR_WORDS * 4, "the epilogue's hard-decision words alias the LLR planes");
     static_assert(NCOLS <= 16);
 };
@@ -440,7 +453,14 @@ struct Decoder {
                 sfor<0, ARG>([&](auto K_) { arg[r][decltype(K_)::value] = B::c(0); });
             }
         });
-        sfor<0, NB>([&](auto E_) { constexpr int e = decltype(E_)::value; if constexpr (GEO::owns(e)) { sv[e] = B::c(0); nz[e] = B::c(0); } });
+        sfor<0, NB>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            if constexpr (GEO::owns(e)) {
+                sv[e] = B::c(0);
+                if constexpr (GEO::nz_in_lds(e)) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::nz_addr(e))), B::c(0));
+                else nz[e] = B::c(0);
+            }
+        });
         sfor<0, NCOLS>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
             if constexpr (GEO::owns_col(c)) {
@@ -697,7 +717,10 @@ struct Decoder {
                     }
                     A::template sat_add_x<true>(nv, su, x);                          // new_v_ai = va (-sat) u            (:421)
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
-                    const V drop = op3<TT_DROP>(nz[e], sv[e], nv[MG]);
+                    V nz_old;
+                    if constexpr (GEO::nz_in_lds(e)) nz_old = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::nz_addr(e))));
+                    else nz_old = nz[e];
+                    const V drop = op3<TT_DROP>(nz_old, sv[e], nv[MG]);
                     // v = drop ? 0 : nv is never formed: its sign, its key and "v != 0" follow from nv and drop directly.
                     // key of |v|: planes 1..7 = v ^ sign, plane 0 = sign -- except for -128, which is +127's key
                     V key[PL];
@@ -706,7 +729,8 @@ struct Decoder {
                     const V all1 = A::template and_planes<1, MG>(key);
                     key[0] = op3<TT_KEY0>(vs, all1, key[MG]);
                     sv[e] = vs;
-                    nz[e] = A::template or_planes<1, PL>(vs, key);
+                    if constexpr (GEO::nz_in_lds(e)) b.lds_write32(B::add(B::shl(lane, 2), B::c(GEO::nz_addr(e))), A::template or_planes<1, PL>(vs, key));
+                    else nz[e] = A::template or_planes<1, PL>(vs, key);
                     if constexpr (e == GEO::first_edge(r)) {
                         // the row's running state STARTS with this edge: every key is <= 254 = the key of maxval (decoder.rs:414-415), so
                         // after one insertion min1 = this key and min2 = 254 whatever the key -- no compare; the arg-min slot is this
@@ -736,7 +760,7 @@ struct Decoder {
                     // The instruction selector orders a basic block by its data flow alone and would compute values whose next use is
                     // an iteration away (the new v's zero-ness, the row minima) at the END of the block, holding their operands -- seven
                     // key planes per edge -- in registers until then.  An opaque use pins each update where it is written (rate 2/3).
-                    pin_update(sv[e]); pin_update(nz[e]); pin_update(Sn[r]); pin_update(Pn[r]);
+                    pin_update(sv[e]); if constexpr (!GEO::nz_in_lds(e)) pin_update(nz[e]); pin_update(Sn[r]); pin_update(Pn[r]);
                     sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; pin_update(W1[r][k]); pin_update(W2[r][k]); });
                     sfor<0, ARG>([&](auto K_) { pin_update(argn[r][decltype(K_)::value]); });
                     if constexpr (e == GEO::last_edge(r) && !GEO::shared_row(r)) finish_row<r>();
