@@ -138,5 +138,26 @@ def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
             continue
         assert not any(t.startswith("scratch_") for t in body), name
         assert sum(1 for t in body if t.startswith("s_barrier")) == 2 * 2 + 2, name           # two halves x two per iteration, + one per half before the epilogue
+        # Round 5, second pass (profiles/r05_kbench/permute_pipeline.txt): a wave at two waves per SIMD pays for every instruction it
+        # issues, so the properties below are performance, not style.
+        perm = sum(1 for t in body if t.startswith("ds_bpermute_b32"))
+        waits = sum(1 for t in body if t.startswith("s_waitcnt"))
+        if "ILi3E" in name:
+            # TM1280: a codeword is one quad of lanes -- its lane permutations are DPP quad rotations, not LDS permutes
+            assert perm == 0, f"{name}: {perm} ds_bpermute_b32 (expected DPP quad_perm moves)"
+            assert sum(1 for t in body if t.startswith("v_mov_b32_dpp")) >= 200, name
+        else:
+            # TM5120: one s_waitcnt per permutation job (eight permutes), not one per plane
+            assert perm >= 400, name
+            assert waits < perm, f"{name}: {waits} s_waitcnt for {perm} ds_bpermute_b32 (whole kernel): the per-job wait is gone"
         seen += 1
     assert seen == 2
+    # the rate-2/3 kernels run the same one-wait-per-job schedule; the rate-1/2 kernels cannot (no registers) but keep four edges'
+    # "v != 0" planes in LDS instead of scratch
+    for name, body in kernels.items():
+        if "decode_ms_bs_kernel" not in name:
+            continue
+        perm = sum(1 for t in body if t.startswith("ds_bpermute_b32"))
+        waits = sum(1 for t in body if t.startswith("s_waitcnt"))
+        if "ILi4E" in name or "ILi7E" in name:
+            assert waits < perm, f"{name}: {waits} s_waitcnt for {perm} ds_bpermute_b32"
