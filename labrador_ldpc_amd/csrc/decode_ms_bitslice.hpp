@@ -89,8 +89,10 @@ inline constexpr int TT_OVF_NS = tt_of([](bool a7, bool s, bool sum7) -> bool { 
 inline constexpr int TT_BORROW = tt_of([](bool b, bool a, bool br) -> bool { return (!a && b) || (br && (!a || b)); });
 // self-correction: (nz, sv, nv7) -> the old v was non-zero and the new sign differs
 inline constexpr int TT_DROP = tt_of([](bool nz, bool sv, bool nv7) -> bool { return nz && (sv != nv7); });
-// plane k + 1 of the key of v = drop ? 0 : nv:  (nv_k, nv7, drop) -> (nv_k ^ nv7) & ~drop
-inline constexpr int TT_KEYBIT = tt_of([](bool x, bool s, bool drop) -> bool { return (x != s) && !drop; });
+// the same from the wrapped difference: (drop, ovf, sign) -> the value a forced plane takes, else the sign to XOR with
+inline constexpr int TT_FVAL = tt_of([](bool drop, bool ovf, bool s) -> bool { return drop ? false : (ovf ? true : s); });
+// (difference plane, force, fval) -> force ? fval : difference ^ fval
+inline constexpr int TT_FORCE = tt_of([](bool d, bool force, bool fval) -> bool { return force ? fval : (d != fval); });
 // plane 0 of the key: (sign, all1, key7) -> sign unless the value is -128
 inline constexpr int TT_KEY0 = tt_of([](bool s, bool all1, bool k7) -> bool { return s && !(all1 && k7); });
 static_assert(TT_XOR3 == 0x96 && TT_MAJ == 0xE8 && TT_MUX == 0xCA && TT_OR3 == 0xFE && TT_AND3 == 0x80);
@@ -354,6 +356,21 @@ struct Arith {
     // xr[k] = magnitude[k] ^ sr (one's complement if negative; the
     // + 1 rides on the carry-in sr).  INV: acc (-sat) w instead -- every bit of the addend inverted, which costs nothing: the truth
     // tables absorb the complements.  So one xr serves the variable side (add u) and the check side (subtract the same u) of an edge.
+    // the same sum WITHOUT the saturation's selects: the wrapped sum planes and the overflow flag (the check side forms the key of the
+    // saturated value from these directly: Decoder::columns)
+    template <bool INV>
+    static BS_FN void add_x_wrapped(const V (&acc)[PL], V sr, const V (&xr)[MG], V (&sum)[PL], V &ovf)
+    {
+        sum[0] = op3<TT_XOR3>(acc[0], xr[0], sr);
+        V c = INV ? op3<TT_MAJ_NBC>(acc[0], xr[0], sr) : op3<TT_MAJ>(acc[0], xr[0], sr);
+        sfor<1, MG>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            sum[k] = INV ? op3<TT_XNOR3>(acc[k], xr[k], c) : op3<TT_XOR3>(acc[k], xr[k], c);
+            c = INV ? op3<TT_MAJ_NB>(acc[k], xr[k], c) : op3<TT_MAJ>(acc[k], xr[k], c);
+        });
+        sum[MG] = INV ? op3<TT_XNOR3>(acc[MG], sr, c) : op3<TT_XOR3>(acc[MG], sr, c);
+        ovf = INV ? op3<TT_OVF_NS>(acc[MG], sr, sum[MG]) : op3<TT_OVF>(acc[MG], sr, sum[MG]);
+    }
     template <bool INV>
     static BS_FN void sat_add_x(V (&acc)[PL], V sr, const V (&xr)[MG])
     {
@@ -470,34 +487,31 @@ struct Decoder {
         });
     }
 
-    // "this edge holds the row's min1": arg[r] == slot
+    // "this edge holds the row's min1": arg[r] == slot.  An AND over ARG literals (plane k, or its complement where bit k of SLOT is 0):
+    // three literals in the first instruction, two more per further one -- the complements ride in the truth tables
     template <int R, int SLOT>
     BS_FN V is_arg() const
     {
-        // AND over the ARG planes of (plane == bit of SLOT); planes taken three at a time
-        V acc = B::c(0xFFFFFFFFu);
-        auto lit = [&](int k) { return ((SLOT >> k) & 1) ? arg[R][k] : B::not_(arg[R][k]); };
-        if constexpr (ARG == 0) return acc;
-        else {
-            // fold with truth tables that absorb the complements: f = acc & (x0 ^ ~s0) & (x1 ^ ~s1)
-            constexpr int s0 = SLOT & 1, s1 = (SLOT >> 1) & 1;
-            if constexpr (ARG == 1) return lit(0);
-            else {
-                // first pair
-                constexpr int tt2 = (s0 && s1) ? 0x88 : (s0 && !s1) ? 0x22 : (!s0 && s1) ? 0x44 : 0x11;     // f(a=x1? ..) see below
-                // op3 inputs (a, b, c) = (unused acc = all ones, x1, x0): value must be (x0 == s0) & (x1 == s1); index bit1 = x1, bit0 = x0
-                // with a = 1 the relevant entries are 4..7, with a = 0 entries 0..3; fill both halves identically
-                V r2 = op3<tt2>(acc, arg[R][1], arg[R][0]);
-                if constexpr (ARG == 2) return r2;
-                else {
-                    V r = r2;
-                    sfor<2, ARG>([&](auto K_) {
-                        constexpr int k = decltype(K_)::value;
-                        r = ((SLOT >> k) & 1) ? B::and_(r, arg[R][k]) : B::andn(r, arg[R][k]);          // r & x  /  r & ~x
-                    });
-                    return r;
-                }
-            }
+        constexpr auto bit = [](int k) { return (SLOT >> k) & 1; };
+        if constexpr (ARG == 0) return B::c(0xFFFFFFFFu);
+        else if constexpr (ARG == 1) return bit(0) ? arg[R][0] : B::not_(arg[R][0]);
+        else if constexpr (ARG == 2) {
+            constexpr int tt = tt_of([](bool, bool x1, bool x0) -> bool { return x1 == (bool)((SLOT >> 1) & 1) && x0 == (bool)(SLOT & 1); });
+            return op3<tt>(arg[R][1], arg[R][1], arg[R][0]);
+        } else {
+            constexpr int tt3 = tt_of([](bool x2, bool x1, bool x0) -> bool {
+                return x2 == (bool)((SLOT >> 2) & 1) && x1 == (bool)((SLOT >> 1) & 1) && x0 == (bool)(SLOT & 1);
+            });
+            V r = op3<tt3>(arg[R][2], arg[R][1], arg[R][0]);
+            sfor<0, (ARG - 3) / 2>([&](auto I_) {
+                constexpr int k = 3 + 2 * decltype(I_)::value;
+                constexpr int tt = tt_of([](bool acc, bool xb, bool xa) -> bool {
+                    return acc && xb == (bool)((SLOT >> (3 + 2 * decltype(I_)::value + 1)) & 1) && xa == (bool)((SLOT >> (3 + 2 * decltype(I_)::value)) & 1);
+                });
+                r = op3<tt>(r, arg[R][k + 1], arg[R][k]);
+            });
+            if constexpr ((ARG - 3) % 2 == 1) r = bit(ARG - 1) ? B::and_(r, arg[R][ARG - 1]) : B::andn(r, arg[R][ARG - 1]);
+            return r;
         }
     }
 
@@ -715,17 +729,25 @@ struct Decoder {
                         edge_u<e>(su, mg);
                         sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = B::xor_(mg[k], su); });
                     }
-                    A::template sat_add_x<true>(nv, su, x);                          // new_v_ai = va (-sat) u            (:421)
+                    // new_v_ai = va (-sat) u (:421) is never formed either: the WRAPPED difference and its overflow flag are enough.  The
+                    // saturated value's sign is the marginal's on overflow, the difference's otherwise; its magnitude planes ^ sign are all
+                    // ones on overflow (+127, and -128 which takes +127's key).
+                    V dsum[PL], ovf;
+                    A::template add_x_wrapped<true>(nv, su, x, dsum, ovf);
+                    const V nsign = op3<TT_MUX>(ovf, nv[MG], dsum[MG]);
                     // self-correction (:422-426): keep unless the old v was non-zero with the other sign
                     V nz_old;
                     if constexpr (GEO::nz_in_lds(e)) nz_old = b.lds_read32(B::add(B::shl(lane, 2), B::c(GEO::nz_addr(e))));
                     else nz_old = nz[e];
-                    const V drop = op3<TT_DROP>(nz_old, sv[e], nv[MG]);
-                    // v = drop ? 0 : nv is never formed: its sign, its key and "v != 0" follow from nv and drop directly.
-                    // key of |v|: planes 1..7 = v ^ sign, plane 0 = sign -- except for -128, which is +127's key
+                    const V drop = op3<TT_DROP>(nz_old, sv[e], nsign);
+                    // v = drop ? 0 : nv: its sign, its key and "v != 0".  key of |v|: planes 1..7 = v ^ sign, plane 0 = sign -- except for
+                    // -128, which is +127's key.  A key plane is FORCED to 0 where v is dropped and to 1 where the difference overflowed:
+                    // (force, value) select among {difference ^ sign, 0, 1} in one instruction per plane
+                    const V force = B::or_(ovf, drop);
+                    const V fval = op3<TT_FVAL>(drop, ovf, nsign);
                     V key[PL];
-                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = op3<TT_KEYBIT>(nv[k], nv[MG], drop); });
-                    const V vs = B::andn(nv[MG], drop);                              // sign of the new v
+                    sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; key[k + 1] = op3<TT_FORCE>(dsum[k], force, fval); });
+                    const V vs = B::andn(nsign, drop);                               // sign of the new v
                     const V all1 = A::template and_planes<1, MG>(key);
                     key[0] = op3<TT_KEY0>(vs, all1, key[MG]);
                     sv[e] = vs;
