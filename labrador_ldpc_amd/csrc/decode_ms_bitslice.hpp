@@ -215,6 +215,14 @@ struct Geo {
         for (int e = 0; e < NB; ++e) if (owns(e) && P.blk[e].row == r && (best < 0 || proc_pos(e) > proc_pos(best))) best = e;
         return best;
     }
+    // the owned edge of block row r that follows first_edge(r) in that order (-1: the row has one owned edge)
+    static constexpr int second_edge(int r)
+    {
+        int best = -1;
+        for (int e = 0; e < NB; ++e)
+            if (owns(e) && P.blk[e].row == r && e != first_edge(r) && (best < 0 || proc_pos(e) < proc_pos(best))) best = e;
+        return best;
+    }
     // the order in which an iteration uses the permutation-table entries (entry 2x = check -> variable alignment of exchanged edge x,
     // 2x + 1 = the way back): block column by block column in COL_ORDER, the variable side's edges, then the check side's
     struct PermOrder { int idx[2 * NB + 1]; int pos[2 * NB + 1]; };
@@ -767,13 +775,23 @@ struct Decoder {
                         Sn[r] = B::xor_(Sn[r], vs);                                  // product of the signs (:438-441)
                         // two running minima (:430-434)
                         const V lt1 = A::less_than(key, W1[r]);
-                        const V lt2 = A::less_than(key, W2[r]);
-                        sfor<0, PL>([&](auto K_) {
-                            constexpr int k = decltype(K_)::value;
-                            const V t = op3<TT_MUX>(lt2, key[k], W2[r][k]);
-                            W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], t);
-                            W1[r][k] = op3<TT_MUX>(lt1, key[k], W1[r][k]);
-                        });
+                        if constexpr (e == GEO::second_edge(r)) {
+                            // min2 is still 254, the largest key there is: "key < min2 ? key : min2" IS key (a key that is not
+                            // smaller is 254 itself) -- the row's second edge needs one compare and two selects per plane
+                            sfor<0, PL>([&](auto K_) {
+                                constexpr int k = decltype(K_)::value;
+                                W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], key[k]);
+                                W1[r][k] = op3<TT_MUX>(lt1, key[k], W1[r][k]);
+                            });
+                        } else {
+                            const V lt2 = A::less_than(key, W2[r]);
+                            sfor<0, PL>([&](auto K_) {
+                                constexpr int k = decltype(K_)::value;
+                                const V t = op3<TT_MUX>(lt2, key[k], W2[r][k]);
+                                W2[r][k] = op3<TT_MUX>(lt1, W1[r][k], t);
+                                W1[r][k] = op3<TT_MUX>(lt1, key[k], W1[r][k]);
+                            });
+                        }
                         sfor<0, ARG>([&](auto K_) {
                             constexpr int k = decltype(K_)::value;
                             argn[r][k] = ((slot >> k) & 1) ? B::or_(argn[r][k], lt1) : B::andn(argn[r][k], lt1);

@@ -12,7 +12,7 @@
 // the arg-min slot -- over ALL the row's edges, and a row's edges lie in both halves (block rows 1 and 2; row 0's three edges are all
 // wave 1's).  Each wave accumulates the row state over ITS edges.  Once per iteration wave 0 publishes its partial state of row 1 and
 // wave 1 of row 2 (a 24-plane LDS buffer per wave); after a barrier each wave merges the row the OTHER published into its own partial
-// state of that row (the two smallest keys of a union are min(a1, b1) and min(max(a1, b1), min(a2, b2)); signs and parities XOR; the
+// state of that row (the two smallest keys of a union are min(a1, b1) and min(max(a1, b1), the winner's min2); signs and parities XOR; the
 // arg-min slot follows the smaller min1, wave 0's on a tie), finishes the row (minima back to magnitudes: the row's new OLD state) and
 // writes that into the other's buffer; after a second barrier each wave fetches the finished state of the row it published.  Both waves then hold the same state.  One merge per wave and
 // two workgroup barriers per iteration (two waves with balanced work: they arrive together).
@@ -152,13 +152,14 @@ struct SplitGroup {
         V take;
         if constexpr (HALF == 0) take = A::less_than(o1, d.W1[R]);                  // other (wave 1) strictly smaller
         else take = B::not_(A::less_than(d.W1[R], o1));                             // mine (wave 1) not strictly smaller
+        // the union's second smallest: the loser of the min1 comparison against the WINNER's side's min2 (the loser's own min2 is
+        // no smaller than the loser) -- one more compare, not two
         V hi[PL], lo[PL];
-        const V lt2 = A::less_than(o2, d.W2[R]);
         sfor<0, PL>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             hi[k] = op3<TT_MUX>(take, d.W1[R][k], o1[k]);                            // the larger of the two min1
+            lo[k] = op3<TT_MUX>(take, o2[k], d.W2[R][k]);                            // min2 of the side whose min1 won
             d.W1[R][k] = op3<TT_MUX>(take, o1[k], d.W1[R][k]);
-            lo[k] = op3<TT_MUX>(lt2, o2[k], d.W2[R][k]);                             // the smaller of the two min2
         });
         const V lt3 = A::less_than(hi, lo);
         sfor<0, PL>([&](auto K_) { constexpr int k = decltype(K_)::value; d.W2[R][k] = op3<TT_MUX>(lt3, hi[k], lo[k]); });
