@@ -39,6 +39,14 @@
 //    edge) and REPLACES the row's old state the moment its last edge is done, so that old and new state of a row are live together
 //    only between its first and its last edge.  Hard decisions live in LDS where that frees the registers for one more wave per
 //    SIMD (Geo::HARD_LDS).
+//
+//  * WHAT AN INSTRUCTION COSTS (round 5, profiles/r05_kbench/permute_pipeline.txt).  At two waves per SIMD a wave is bound by ISSUE
+//    -- one instruction of any kind per ~4.6 cycles, plus ~3.9 ns of SIMD time per ds_bpermute -- so the loop is written to issue
+//    few: the next permutation job's eight ds_bpermute are in flight behind the current job's arithmetic, which lets ONE s_waitcnt
+//    per job replace eight counted ones (Geo::PIPE); an exchanged edge's (sign, magnitude ^ sign) planes are kept from the variable
+//    side for the check side (Geo::KEEP); the check side never forms the saturated va (-sat) u, it forms that value's KEY from the
+//    wrapped difference and the overflow flag (Decoder::columns); a row's second edge needs one compare (min2 is still the largest
+//    key); TM1280 rotates lanes with a DPP quad_perm instead of ds_bpermute (Geo::QUAD).
 #pragma once
 
 #include <cstdint>
