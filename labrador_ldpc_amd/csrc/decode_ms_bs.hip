@@ -7,8 +7,17 @@
 // codeword, the size of the raw LLRs), the lane-permutation table, one word per lane and block column for the hard decisions (which
 // doubles as the staging slab of the LLR transposition).  Rate 4/5: a group shared by the two waves of a workgroup
 // (decode_ms_bitslice_split.hpp).
+//
+// Compiled TWICE (Makefile, -DBS_TU): unit 1 = the rate-1/2 kernels and the dispatcher, with the default machine scheduler; unit 2 =
+// the rate-2/3 kernels and the two-wave kernels of the rate-4/5 codes, with -mllvm -amdgpu-sched-strategy=iterative-ilp, which is
+// worth +2 % on the two-wave kernels and +0.5 % on rate 2/3 but costs the rate-1/2 kernels (168 registers, spilling) 2.5 %
+// (profiles/r05_kbench/permute_pipeline.txt, section 7).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+
+#ifndef BS_TU
+#error "decode_ms_bs.hip is compiled per unit: -DBS_TU=1 (rate 1/2 + dispatch) or -DBS_TU=2 (rate 2/3, rate 4/5)"
+#endif
 
 #include "decode_ms_bitslice.hpp"
 #include "decode_ms_bitslice_split.hpp"
@@ -89,20 +98,34 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
 
 // i8 LLRs through the bit-sliced kernel; hipErrorInvalidConfiguration for the codes it is not built for (the TC codes: their
 // circulants are not quarter-wise rotations).  llrs 4-byte aligned, output 4-byte aligned (the caller checks).  Rate 4/5: two waves per group.
-hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                      uint32_t maxiters, hipStream_t stream)
+hipError_t launch_decode_ms_bitsliced_unit2(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                            uint32_t maxiters, hipStream_t stream);
+#if BS_TU == 2
+hipError_t launch_decode_ms_bitsliced_unit2(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                            uint32_t maxiters, hipStream_t stream)
 {
     switch (code) {
-#if BS_PLANES == 8
         case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
         case TM1536: return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
         case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
         case TM6144: return bs::launch<TM6144>(llrs, output, iters, success, batch, maxiters, stream);
-#endif                  // (a 16-plane experiment build, tools/bs_alt_build.sh -DBS_PLANES=16, carries the rate-1/2 codes only)
-        case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
-        case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
         default: return hipErrorInvalidConfiguration;
     }
 }
+#else
+hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
+                                      uint32_t maxiters, hipStream_t stream)
+{
+    switch (code) {
+        case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
+#if BS_PLANES == 8
+        default: return launch_decode_ms_bitsliced_unit2(code, llrs, output, iters, success, batch, maxiters, stream);
+#else                   // (a 16-plane experiment build, tools/bs_alt_build.sh -DBS_PLANES=16, carries the rate-1/2 codes only)
+        default: return hipErrorInvalidConfiguration;
+#endif
+    }
+}
+#endif
 
 }  // namespace ldpc

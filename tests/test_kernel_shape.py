@@ -99,11 +99,13 @@ def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
     import tempfile
     llvm = "/opt/rocm/lib/llvm/bin"
     tmp = tempfile.mkdtemp()
-    obj = os.path.join(ROOT, "build", "csrc", "decode_ms_bs.o")
-    subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", obj, "/dev/null"])
-    subprocess.check_call([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat",
-                           f"--output={tmp}/co", "--unbundle"])
-    dis = subprocess.check_output([f"{llvm}/llvm-objdump", "-d", f"{tmp}/co"], text=True).split("\n")
+    dis = []
+    for unit in (1, 2):                                     # decode_ms_bs.hip is compiled per unit (csrc/Makefile: -DBS_TU)
+        obj = os.path.join(ROOT, "build", "csrc", f"decode_ms_bs_{unit}.o")
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat{unit}", obj, "/dev/null"])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={tmp}/fat{unit}",
+                               f"--output={tmp}/co{unit}", "--unbundle"])
+        dis += subprocess.check_output([f"{llvm}/llvm-objdump", "-d", f"{tmp}/co{unit}"], text=True).split("\n")
     kernels, cur = {}, None
     for line in dis:
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
