@@ -11,7 +11,7 @@ R=$(cd $(dirname $0)/.. && pwd); O=$R/build/csrc; D=$R/build/alt; mkdir -p $D
 FLAGS="--offload-arch=gfx950 -O3 -std=c++20 -fPIC -fno-fast-math -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
 for spec in "$@"; do
   name=${spec%%:*}; extra=${spec#*:}
-  ( /opt/rocm/bin/hipcc $FLAGS $extra -DBS_TU=1 -I$O -c $R/labrador_ldpc_amd/csrc/decode_ms_bs.hip -o $D/decode_ms_bs_1_$name.o &&
+  ( /opt/rocm/bin/hipcc $FLAGS $BS1_FLAGS $extra -DBS_TU=1 -I$O -c $R/labrador_ldpc_amd/csrc/decode_ms_bs.hip -o $D/decode_ms_bs_1_$name.o &&
     /opt/rocm/bin/hipcc $FLAGS ${BS2_FLAGS--mllvm -amdgpu-sched-strategy=iterative-ilp} $extra -DBS_TU=2 -I$O -c $R/labrador_ldpc_amd/csrc/decode_ms_bs.hip -o $D/decode_ms_bs_2_$name.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -no-hip-rt -o $D/liblabrador_ldpc_hip_$name.so $(ls $O/*.o | grep -v "decode_ms_bs_[12].o") $D/decode_ms_bs_1_$name.o $D/decode_ms_bs_2_$name.o ) &
 done
