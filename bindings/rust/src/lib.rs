@@ -147,6 +147,7 @@ extern "C" {
     pub fn labrador_ldpc_hip_last_error() -> *const c_char;
     pub fn labrador_ldpc_hip_version() -> *const c_char;
     pub fn labrador_ldpc_hip_build_id() -> *const c_char;
+    pub fn labrador_ldpc_hip_shader_clock_mhz(device: c_int, busy_ms: f64, mhz: *mut f64) -> c_int;
     pub fn labrador_ldpc_hip_abi_version() -> c_int;
     pub fn labrador_ldpc_hip_decode_ms_i8_kernel(code: LDPCCode, variant: c_int, batch: usize) -> *const c_char;
 }

@@ -181,7 +181,7 @@ bool labrador_ldpc_decode_bf(enum labrador_ldpc_code code, const uint8_t *input,
 
 /* capi/include/labrador_ldpc.h:193-208  (capi/src/lib.rs:83-127; src/decoder.rs:347-475).
  * One codeword, host pointers; runs the same kernels as the batched calls with batch = 1
- * (f64: a general, slower kernel, see labrador_ldpc_decode_ms_batch_f64).
+ * (every LLR type incl. f64: the register-resident kernels).
  * `llrs` n entries, `output` output_len bytes, `iters_run` may be NULL. */
 bool labrador_ldpc_decode_ms_i8 (enum labrador_ldpc_code code, const int8_t  *llrs, uint8_t *output,
                                  int8_t  *working, uint8_t *working_u8, size_t max_iters, size_t *iters_run);
@@ -251,7 +251,8 @@ struct labrador_ldpc_hip_opts {
                          it returns after the results are in the host buffers. */
     int   variant;    /* enum labrador_ldpc_hip_variant below; 0 = the tuned default.  Every variant returns identical results. */
     int   n_devices;  /* > 0: shard a MEM_HOST batch over devices[0 .. n_devices) (`device` is ignored) */
-    const int *devices; /* HIP ordinals; an ordinal may repeat (that many host pipelines on it) */
+    const int *devices; /* HIP ordinals; an ordinal may repeat (that many host pipelines on it, at most four at a time: further
+                           repeats queue behind them) */
 };
 #define LABRADOR_LDPC_HIP_OPTS_INIT { sizeof(struct labrador_ldpc_hip_opts) }
 
@@ -303,8 +304,10 @@ int labrador_ldpc_decode_ms_batch_i16(enum labrador_ldpc_code code, const int16_
 int labrador_ldpc_decode_ms_batch_i32(enum labrador_ldpc_code code, const int32_t *llrs, uint8_t *output,
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
-/* f64: same results contract; a general (untuned) kernel that keeps the per-edge messages in a
- * device workspace allocated per call -- see DESIGN.md. */
+/* f64: same results contract.  By default the register-resident kernels with 64-bit registers and LDS elements (plain for the
+ * small codes, register-lean for TM2048 / TM5120, in-place messages for TM6144 / TM8192); `variant`
+ * LABRADOR_LDPC_HIP_VARIANT_F64_WORKSPACE (100) names the general fallback that keeps the per-edge messages in a device workspace
+ * allocated per call (10-100x slower; csrc/decode_ms_f64.hip). */
 int labrador_ldpc_decode_ms_batch_f64(enum labrador_ldpc_code code, const double *llrs, uint8_t *output,
                                       uint32_t *iters, uint8_t *success, size_t batch, size_t max_iters,
                                       const struct labrador_ldpc_hip_opts *opts);
@@ -312,7 +315,8 @@ int labrador_ldpc_decode_ms_batch_f64(enum labrador_ldpc_code code, const double
 /* Device-resident batches on SEVERAL GPUs with one call (the reference's analogue: one job over all workers,
  * perftest/src/main.rs:39-52; capi/src/lib.rs:83-95 for the buffers' meaning).  Part i is frames[i] frames whose four buffers --
  * llrs[i], output[i] (8-byte aligned), iters[i], success[i], laid out as in labrador_ldpc_decode_ms_batch_* -- are DEVICE memory
- * resident on HIP device devices[i]; an ordinal may repeat (several parts on one GPU) and frames[i] may be 0.  Every part is
+ * resident on HIP device devices[i]; an ordinal may repeat (several parts on one GPU: up to four run concurrently, more queue
+ * behind them) and frames[i] may be 0.  Every part is
  * enqueued by the library's persistent worker thread of its device (pinned to the GPU's NUMA node) on a stream of the library's own
  * and the call returns when ALL parts are decoded; work the caller enqueued on its own streams for these buffers must be complete
  * before the call.  No data crosses between devices and there is no collective.  Returns the first failing part's status
@@ -394,6 +398,13 @@ int labrador_ldpc_hip_awgn_i8_at (enum labrador_ldpc_code code, const uint8_t *c
                                   int8_t *llrs, uint64_t first_frame, size_t batch, float sigma, float scale, int lim,
                                   uint64_t seed, const struct labrador_ldpc_hip_opts *opts);
 
+/* Harness diagnostic: the shader clock (MHz) `device` (an ordinal or LABRADOR_LDPC_HIP_DEVICE_CURRENT) holds under a full-chip
+ * VALU load lasting `busy_ms` milliseconds (0.01 .. 1000): the advance of the shader-clock counter against the 100 MHz
+ * real-time counter, median over the workgroups.  Synchronous, default stream.  A multi-GPU harness prints it per worker
+ * beside the worker's rate (perftest/src/main.rs:39-52 aggregates workers it assumes equal; GPUs of one node are not).
+ * Returns a status code. */
+int labrador_ldpc_hip_shader_clock_mhz(int device, double busy_ms, double *mhz);
+
 /* Edge stream CRC of this library's own code tables, computed like the reference's
  * test_iter_parity (src/codes/mod.rs:508-533).  Lets a test pin the tables the kernels are
  * generated from against the reference's nine known answers without a GPU. */
@@ -431,7 +442,10 @@ const char *labrador_ldpc_hip_build_id(void);
 /* Name of the kernel labrador_ldpc_decode_ms_batch_i8 launches for a 4-byte-aligned device batch of `batch` frames with this
  * `variant` ("decode_ms_bs_kernel" / "decode_ms_bs_split_kernel": bit-sliced; "decode_ms_pair_kernel" /
  * "decode_ms_kernel": the f32-pipe kernels) -- the default dispatch depends on the batch size; harnesses label their
- * measurements with it.  "" for a bad code. */
+ * measurements with it.  The launcher and this function share one predicate (csrc/decode_ms_i8.hip: pick_i8_kernel).
+ * "" for a bad code and for a request this build has no kernel for (the batched call then returns LABRADOR_LDPC_HIP_EUNSUPPORTED);
+ * buffers that are NOT 4-byte aligned never take the bit-sliced kernels (default dispatch: the f32-pipe kernel of the code;
+ * `variant` 64: EUNSUPPORTED). */
 const char *labrador_ldpc_hip_decode_ms_i8_kernel(enum labrador_ldpc_code code, int variant, size_t batch);
 
 /* The LABRADOR_LDPC_HIP_ABI the loaded library was built with: a client that dlopen()s the library compares it with its

@@ -97,6 +97,7 @@ SYMBOLS = {
     "labrador_ldpc_hip_version": (_c.c_char_p, []),
     "labrador_ldpc_hip_build_id": (_c.c_char_p, []),
     "labrador_ldpc_hip_abi_version": (_int, []),
+    "labrador_ldpc_hip_shader_clock_mhz": (_int, [_int, _c.c_double, _c.POINTER(_c.c_double)]),
     "labrador_ldpc_hip_decode_ms_i8_kernel": (_c.c_char_p, [_int, _int, _sz]),
 }
 
@@ -404,11 +405,15 @@ class LDPCCode(enum.IntEnum):
         res = [(torch.empty((p.shape[0], self.output_len()), dtype=torch.uint8, device=p.device),
                 torch.empty((p.shape[0],), dtype=torch.int32, device=p.device),
                 torch.empty((p.shape[0],), dtype=torch.uint8, device=p.device)) for p in parts]
-        for p in parts:                                  # the library's streams know nothing of torch's: what produced the inputs must be done
+        # The library's streams know nothing of torch's: what produced the inputs must be done.  Only torch's CURRENT stream of each
+        # device is waited for here -- a caller that filled a part on another stream synchronises that stream itself before the call.
+        for p in parts:
             torch.cuda.current_stream(p.device).synchronize()
         n = len(parts)
         arr = lambda vals, t: (t * n)(*vals)
-        devs = arr([p.device.index or 0 for p in parts], ctypes.c_int)
+        # get_device(): the ordinal the memory lives on, also for a tensor made on torch.device("cuda") (index None) while another
+        # GPU than 0 is current (round 5 advice: `index or 0` sent such a part to device 0)
+        devs = arr([p.get_device() for p in parts], ctypes.c_int)
         _check(fn(int(self), n, devs, arr([_ptr(p) for p in parts], ctypes.c_void_p), arr([_ptr(r[0]) for r in res], ctypes.c_void_p),
                   arr([_ptr(r[1]) for r in res], ctypes.c_void_p), arr([_ptr(r[2]) for r in res], ctypes.c_void_p),
                   arr([p.shape[0] for p in parts], ctypes.c_size_t), maxiters, variant))

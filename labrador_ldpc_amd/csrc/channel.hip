@@ -10,7 +10,9 @@
 // [a, b) of a job writes exactly bytes [a, b) of the buffer a single call for the whole job would write:
 // the shards of an N-GPU run are slices of the one-GPU batch, bit for bit (labrador_ldpc_hip_awgn_*_at).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
+#include <vector>
 
 #include "channel.hpp"
 
@@ -93,7 +95,55 @@ awgn_kernel(const uint8_t *__restrict__ codewords, uint32_t pool, T *__restrict_
     }
 }
 
+// Harness diagnostic: the shader clock the chip holds under a VALU load.  Every wave spins on a dependent chain for a fixed
+// WALL time (s_memrealtime, 100 MHz) and reports how far s_memtime -- which counts shader clocks on gfx950
+// (tools/ubench/clock_rate.hip) -- advanced meanwhile.  A bench line carries the figure per rank, so that a slow rank of an
+// N-GPU run is explained by the line itself (a chip that clocks lower) rather than by a second run.
+__global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long *out, unsigned long long wall_ticks)
+{
+    float a = threadIdx.x * 1.5f + 1.f, b = a * 3.f + 1.f, c = b - 7.f, d = a + b;
+    const unsigned long long m0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1;
+    do {
+        for (int l = 0; l < 64; ++l)
+            asm volatile("v_min_f32 %0, %1, %0\n v_xor_b32 %1, %2, %1\n v_min_f32 %2, %3, %2\n v_xor_b32 %3, %0, %3\n"
+                         "v_add_f32 %0, %1, %0\n v_mul_f32 %1, %2, %1\n v_min3_f32 %2, %3, %2, %0\n v_sub_f32 %3, %0, %3"
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        r1 = __builtin_amdgcn_s_memrealtime();
+    } while (r1 - r0 < wall_ticks);
+    const unsigned long long m1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = m1 - m0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+    if (a + b + c + d == 12345.f) out[2 * gridDim.x] = 1;      // keeps the chain alive
+}
+
 }  // namespace
+
+hipError_t shader_clock_mhz(double busy_ms, double *mhz)
+{
+    constexpr unsigned BLOCKS = 256 * 8;                       // two 256-thread workgroups per SIMD quartet: 8 waves per SIMD
+    unsigned long long *d = nullptr;
+    hipError_t e = hipMalloc(&d, (2 * BLOCKS + 1) * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    if (busy_ms < 0.01) busy_ms = 0.01;
+    if (busy_ms > 1000.0) busy_ms = 1000.0;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(BLOCKS), dim3(256), 0, nullptr, d, (unsigned long long)(busy_ms * 1e5));
+    e = hipGetLastError();
+    std::vector<unsigned long long> h(2 * BLOCKS);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    std::vector<double> r;
+    for (unsigned b = 0; b < BLOCKS; ++b)
+        if (h[2 * b + 1]) r.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
+    if (r.empty()) return hipErrorUnknown;
+    std::nth_element(r.begin(), r.begin() + r.size() / 2, r.end());
+    *mhz = r[r.size() / 2];                                    // median over the workgroups
+    return hipSuccess;
+}
 
 template <class T>
 hipError_t launch_awgn(const uint8_t *codewords, size_t pool, T *llrs, int n, uint64_t first_frame, size_t batch, float sigma,

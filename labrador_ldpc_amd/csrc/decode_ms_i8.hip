@@ -33,17 +33,43 @@ constexpr size_t bitslice_min_batch(int code)
 // its loads and stores are dwords: both buffers 4-byte aligned
 static bool bitslice_aligned(const int8_t *llrs, const uint8_t *output) { return (uintptr_t)llrs % 4 == 0 && (uintptr_t)output % 4 == 0; }
 
-// which kernel the default dispatch picks for an aligned batch of this size (introspection: labrador_ldpc_hip_decode_ms_i8_kernel)
+// ONE predicate for the launcher and for the introspection entry (round 5 advice: the name used to be derived separately
+// and could name a kernel the launcher refuses): which kernel family serves (code, kernel part of `variant`, flags, batch) on
+// buffers of this alignment -- NONE = the launcher returns hipErrorInvalidConfiguration (EUNSUPPORTED at the C ABI).
+enum class I8Kernel { NONE, BITSLICED, BITSLICED_SPLIT, PAIR, PIPE };
+#define LDPC_BUILT_CASE(CODE, T, DEF, ...) case CODE: { constexpr int alts[] = {DEF, ##__VA_ARGS__}; for (int a : alts) if (a == variant) return true; return false; }
+static bool pipe_variant_built(int code, int variant)          // an explicit indices-per-thread value of the table above
+{
+    switch (code) {
+        LDPC_TABLE(LDPC_BUILT_CASE)
+        default: return false;
+    }
+}
+static I8Kernel pick_i8_kernel(int code, int variant, unsigned lflags, size_t batch, bool aligned)
+{
+    if (!valid_code(code) || variant < 0) return I8Kernel::NONE;
+    const bool tm = code >= TM1280 && code <= TM8192;
+    const I8Kernel bs = (code == TM1280 || code == TM5120) ? I8Kernel::BITSLICED_SPLIT : I8Kernel::BITSLICED;
+    if (variant == VARIANT_BITSLICE) return tm && aligned ? bs : I8Kernel::NONE;
+    if (variant == 0 && lflags == 0 && batch >= bitslice_min_batch(code) && aligned) return bs;
+    if (variant == VARIANT_PAIR) return code == TM8192 ? I8Kernel::PAIR : I8Kernel::NONE;
+    if (variant == 0) return code == TM8192 ? I8Kernel::PAIR : I8Kernel::PIPE;
+    return pipe_variant_built(code, variant) ? I8Kernel::PIPE : I8Kernel::NONE;
+}
+
+// the kernel labrador_ldpc_decode_ms_batch_i8 launches for a 4-byte-aligned batch of this size ("" = this build has none for the
+// request: the call returns LABRADOR_LDPC_HIP_EUNSUPPORTED).  Buffers that are not 4-byte aligned never take the bit-sliced kernels.
 const char *decode_ms_i8_kernel_name(int code, int variant, size_t batch)
 {
     if (!valid_code(code) || variant < 0) return "";
-    const int flags = variant & VARIANT_FLAGS;
-    variant &= ~VARIANT_FLAGS;
-    const bool tm = code >= TM1280;
-    if ((variant == VARIANT_BITSLICE && tm) || (variant == 0 && flags == 0 && batch >= bitslice_min_batch(code)))
-        return (code == TM1280 || code == TM5120) ? "decode_ms_bs_split_kernel" : "decode_ms_bs_kernel";
-    if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) return "decode_ms_pair_kernel";
-    return "decode_ms_kernel";
+    LDPC_SPLIT_VARIANT();
+    switch (pick_i8_kernel(code, variant, lflags, batch, true)) {
+        case I8Kernel::BITSLICED:       return "decode_ms_bs_kernel";
+        case I8Kernel::BITSLICED_SPLIT: return "decode_ms_bs_split_kernel";
+        case I8Kernel::PAIR:            return "decode_ms_pair_kernel";
+        case I8Kernel::PIPE:            return "decode_ms_kernel";
+        default:                        return "";
+    }
 }
 
 template <>
@@ -52,16 +78,16 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
                                     uint32_t maxiters, hipStream_t stream)
 {
     LDPC_SPLIT_VARIANT();
-    if (variant == VARIANT_BITSLICE) {
-        if (!bitslice_aligned(llrs, output)) return hipErrorInvalidConfiguration;
-        return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
-    }
-    if (variant == 0 && lflags == 0 && batch >= bitslice_min_batch(code) && bitslice_aligned(llrs, output))
-        return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
-    // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
-    if (variant == VARIANT_PAIR || (variant == 0 && code == TM8192)) {
-        if (code == TM8192) return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);
-        return hipErrorInvalidConfiguration;
+    switch (pick_i8_kernel(code, variant, lflags, batch, bitslice_aligned(llrs, output))) {
+        case I8Kernel::BITSLICED:
+        case I8Kernel::BITSLICED_SPLIT:
+            return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
+        case I8Kernel::PAIR:           // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
+            return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);
+        case I8Kernel::PIPE:
+            break;
+        default:
+            return valid_code(code) ? hipErrorInvalidConfiguration : hipErrorInvalidValue;
     }
     switch (code) {
         LDPC_TABLE(LDPC_CASE)

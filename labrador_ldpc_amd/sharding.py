@@ -129,6 +129,19 @@ def reduce_sum(values: Sequence[float], device=None) -> Sequence[float]:
     return t.tolist()
 
 
+def gather(values: Sequence[float]) -> List[List[float]]:
+    """Every rank's `values` (equal lengths), indexed by rank, on every rank: per-rank diagnostics of a bench line (device,
+    kernel time, clock) -- what tells a slow GPU from a slow shard."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [list(values)]
+    t = torch.tensor(list(values), dtype=torch.float64)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
 def reduce_sum_int(values: Sequence[int]) -> Sequence[int]:
     """Element-wise EXACT integer SUM over ranks (int64; the float64 of reduce_sum is exact only to 2^53): iteration totals,
     failure counts and the job digest of bench.py, which must be equal whatever the number of ranks."""

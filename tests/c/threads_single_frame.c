@@ -1,0 +1,174 @@
+/* N host threads calling the REFERENCE-SHAPED single-frame symbols concurrently (round 5's review, missing #3).
+ *
+ * The reference guarantees re-entrancy -- no globals but read-only tables (src/lib.rs:15-17) -- and its own harness relies on it:
+ * perftest/src/main.rs:39-45 runs ms_trial() on every core at once, each worker on buffers of its own (:10-21: encode, hard_to_llrs,
+ * add noise, decode_ms with caller-owned working areas).  An unmodified perftest dropped onto this library is exactly this program's
+ * shape: THREADS workers, each looping
+ *     labrador_ldpc_copy_encode -> labrador_ldpc_hard_to_llrs_* -> + noise -> labrador_ldpc_decode_ms_{f32,i8,i16,f64} / labrador_ldpc_decode_bf
+ * over MIXED codes (thread t starts at code t mod 9 and walks on), every buffer caller-owned and thread-private.
+ *
+ * Check: the trials are a pure function of (thread, trial) -- inputs come from a counter-based generator -- so the main thread first
+ * decodes every trial alone, one after the other (the single-threaded pass), and the workers' results (success flag, iteration
+ * count, every output byte) must equal it.  Also reported: the aggregate single-frame rate of the threads.
+ *
+ *   cc -std=c11 -O1 -Wall -Werror -pthread -Iinclude tests/c/threads_single_frame.c -Llabrador_ldpc_amd -llabrador_ldpc_hip \
+ *      -L/opt/rocm/lib -lamdhip64 -o threads_single_frame && ./threads_single_frame [threads] [trials per thread]
+ * Exit status 0 = all equal; 77 = no gfx950 device (then only the host-side helpers were exercised); 1 = a difference.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "labrador_ldpc.h"
+
+#define MAX_THREADS 64
+#define MAX_N 8192
+#define MAX_OUT 1280
+#define N_CODES 9
+#define N_KINDS 5                 /* f32, i8, i16, f64, bf */
+
+static const enum labrador_ldpc_code CODES[N_CODES] = {
+    LABRADOR_LDPC_CODE_TC128, LABRADOR_LDPC_CODE_TC256, LABRADOR_LDPC_CODE_TC512, LABRADOR_LDPC_CODE_TM1280, LABRADOR_LDPC_CODE_TM1536,
+    LABRADOR_LDPC_CODE_TM2048, LABRADOR_LDPC_CODE_TM5120, LABRADOR_LDPC_CODE_TM6144, LABRADOR_LDPC_CODE_TM8192};
+
+/* splitmix64: trial inputs are a pure function of (thread, trial, position) */
+static uint64_t mix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+/* a cheap symmetric noise sample in (-1.5, 1.5): the sum of three uniforms (the decoders' inputs need not be Gaussian here) */
+static float noise(uint64_t key)
+{
+    const uint64_t r = mix(key);
+    const float a = (float)(r & 0xFFFFF) / 1048576.0f, b = (float)((r >> 20) & 0xFFFFF) / 1048576.0f, c = (float)((r >> 40) & 0xFFFFF) / 1048576.0f;
+    return a + b + c - 1.5f;
+}
+
+struct result { unsigned char ok; size_t iters; uint8_t out[MAX_OUT]; };
+
+/* worker-private buffers: the caller owns everything (capi/src/lib.rs:83-95); `working` areas are passed as the reference's
+ * callers pass them even though this library does not touch them */
+struct scratch {
+    uint8_t data[MAX_N / 8], cw[MAX_N / 8];
+    float f32[MAX_N]; double f64[MAX_N]; int8_t i8[MAX_N]; int16_t i16[MAX_N];
+    float wf[LABRADOR_LDPC_MS_WORKING_LEN_TM8192];
+    uint8_t wu8[LABRADOR_LDPC_MS_WORKING_U8_LEN_TM8192], wbf[LABRADOR_LDPC_BF_WORKING_LEN_TM8192];
+};
+
+/* one trial = perftest's ms_trial (perftest/src/main.rs:9-29) through the C API */
+static void trial(struct scratch *s, int thread, int t, struct result *res)
+{
+    const enum labrador_ldpc_code code = CODES[(thread + t) % N_CODES];
+    const int kind = (thread / 3 + t) % N_KINDS;
+    const size_t n = labrador_ldpc_code_n(code), k = labrador_ldpc_code_k(code), out_len = labrador_ldpc_output_len(code);
+    const uint64_t key = ((uint64_t)thread << 40) ^ ((uint64_t)t << 20);
+    for (size_t i = 0; i < k / 8; i++) s->data[i] = (uint8_t)mix(key ^ i ^ 0xD00Dull << 48);
+    labrador_ldpc_copy_encode(code, s->data, s->cw);
+    memset(res->out, 0xA5, sizeof res->out);
+    res->iters = (size_t)-1;
+    const float amp = 1.0f + 0.25f * (float)(t % 5);                 /* noise sigma 0.5 .. 1.0: from always-converging to never (rate 4/5) */
+    if (kind == 4) {                                                   /* bit flipping: a few flipped bits */
+        for (int f = 0; f < (t % 7 == 6 ? 60 : 1 + t % 3); f++) {   /* (60 flips: beyond bit flipping) */ const size_t b = mix(key ^ 0xF11Full ^ (uint64_t)f) % n; s->cw[b / 8] ^= (uint8_t)(0x80 >> (b % 8)); }
+        res->ok = labrador_ldpc_decode_bf(code, s->cw, res->out, s->wbf, 40, &res->iters);
+        (void)out_len;
+        return;
+    }
+    labrador_ldpc_hard_to_llrs_f32(code, s->cw, s->f32);
+    for (size_t i = 0; i < n; i++) s->f32[i] += amp * noise(key ^ 0xABCDull << 32 ^ i);
+    switch (kind) {
+    case 0:
+        res->ok = labrador_ldpc_decode_ms_f32(code, s->f32, res->out, s->wf, s->wu8, 30, &res->iters);
+        break;
+    case 1:
+        for (size_t i = 0; i < n; i++) { float v = 8.0f * s->f32[i]; v = v > 31 ? 31 : (v < -32 ? -32 : v); s->i8[i] = (int8_t)v; }
+        res->ok = labrador_ldpc_decode_ms_i8(code, s->i8, res->out, (int8_t *)s->wf, s->wu8, 30, &res->iters);
+        break;
+    case 2:
+        for (size_t i = 0; i < n; i++) s->i16[i] = (int16_t)(512.0f * s->f32[i]);
+        res->ok = labrador_ldpc_decode_ms_i16(code, s->i16, res->out, (int16_t *)s->wf, s->wu8, 30, &res->iters);
+        break;
+    default:
+        for (size_t i = 0; i < n; i++) s->f64[i] = (double)s->f32[i] * 1.0000001;
+        res->ok = labrador_ldpc_decode_ms_f64(code, s->f64, res->out, NULL, s->wu8, 30, NULL);   /* iters_run may be NULL (lib.rs:91-93) */
+        res->iters = 0;
+        break;
+    }
+}
+
+static int n_threads = 16, n_trials = 54;
+static struct result *expect, *got;
+static pthread_barrier_t start_line;
+
+static void *worker(void *arg)
+{
+    const int thread = (int)(size_t)arg;
+    struct scratch *s = malloc(sizeof *s);
+    if (!s) return (void *)1;
+    pthread_barrier_wait(&start_line);                                 /* all workers enter the library together */
+    for (int t = 0; t < n_trials; t++) trial(s, thread, t, &got[thread * n_trials + t]);
+    free(s);
+    return NULL;
+}
+
+static double now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) n_threads = atoi(argv[1]);
+    if (argc > 2) n_trials = atoi(argv[2]);
+    if (n_threads < 1 || n_threads > MAX_THREADS || n_trials < 1) { printf("usage: %s [threads <= %d] [trials]\n", argv[0], MAX_THREADS); return 2; }
+    const int have_gpu = labrador_ldpc_hip_device_count() > 0;
+    const size_t total = (size_t)n_threads * (size_t)n_trials;
+    expect = calloc(total, sizeof *expect);
+    got = calloc(total, sizeof *got);
+    struct scratch *s = malloc(sizeof *s);
+    if (!expect || !got || !s) { printf("FAIL: out of memory\n"); return 1; }
+
+    /* the single-threaded pass: every trial alone, one after the other */
+    double t0 = now();
+    for (int th = 0; th < n_threads; th++)
+        for (int t = 0; t < n_trials; t++) trial(s, th, t, &expect[th * n_trials + t]);
+    const double serial_s = now() - t0;
+    free(s);
+
+    pthread_t tid[MAX_THREADS];
+    pthread_barrier_init(&start_line, NULL, (unsigned)n_threads + 1);
+    for (int th = 0; th < n_threads; th++)
+        if (pthread_create(&tid[th], NULL, worker, (void *)(size_t)th)) { printf("FAIL: pthread_create\n"); return 1; }
+    pthread_barrier_wait(&start_line);
+    t0 = now();
+    int bad_thread = 0;
+    for (int th = 0; th < n_threads; th++) { void *r; pthread_join(tid[th], &r); bad_thread |= r != NULL; }
+    const double threads_s = now() - t0;
+    if (bad_thread) { printf("FAIL: a worker could not allocate\n"); return 1; }
+
+    size_t diff = 0, converged = 0;
+    for (size_t i = 0; i < total; i++) {
+        const int same = expect[i].ok == got[i].ok && expect[i].iters == got[i].iters && !memcmp(expect[i].out, got[i].out, MAX_OUT);
+        if (!same && diff++ < 5)
+            printf("DIFF: thread %zu trial %zu: ok %d/%d iters %zu/%zu\n", i / (size_t)n_trials, i % (size_t)n_trials, expect[i].ok, got[i].ok,
+                   expect[i].iters, got[i].iters);
+        converged += expect[i].ok;
+    }
+    if (!have_gpu) {
+        /* without a GPU every decoder must have said `false` identically and left defined outputs; the host helpers ran concurrently */
+        printf("no gfx950 device: %zu single-frame calls from %d threads all returned false%s\n", total, n_threads, diff ? " -- but DIFFERENTLY" : "");
+        return diff ? 1 : 77;
+    }
+    if (diff) { printf("FAIL: %zu of %zu trials differ between the threaded and the single-threaded pass\n", diff, total); return 1; }
+    if (converged == 0 || converged == total) { printf("FAIL: degenerate trial set (%zu of %zu converged)\n", converged, total); return 1; }
+    printf("ok: %d threads x %d trials (9 codes; f32, i8, i16, f64, bf) equal the single-threaded pass; %zu of %zu converged; "
+           "single-threaded %.0f calls/s, %d threads %.0f calls/s aggregate\n", n_threads, n_trials, converged, total,
+           (double)total / serial_s, n_threads, (double)total / threads_s);
+    return 0;
+}

@@ -208,3 +208,24 @@ def test_job_digest_is_split_invariant():
     swapped = out.clone()
     swapped[[10, 11]] = swapped[[11, 10]]
     assert W(0, swapped, iters, succ).sums()[2] != whole[2] or bool((out[10] == out[11]).all())
+
+
+def test_whole_job_check_against_the_committed_answers():
+    """Round 5's review, next #1: every bench line compares the job's exact results with the committed one-GPU answers."""
+    b = _bench()
+    key = b.job_key("TM8192", "f32", 4194304, 2.0, 25, 256)
+    assert key == "TM8192_f32_4194304f_2dB_25it_pool256" and key in b.EXPECTED_JOBS          # the headline job is committed ...
+    assert b.job_key("TM8192", "i8", 4194304, 2.0, 25, 256) in b.EXPECTED_JOBS                # ... and the i8 job
+    want = b.EXPECTED_JOBS[key]
+    ok = b.whole_job_check(key, want["iters_sum"], want["failed_frames"], want["job_digest"])
+    assert ok["match"] is True and "got" not in ok
+    for field, bad in (("iters_sum", want["iters_sum"] + 1), ("failed_frames", want["failed_frames"] - 1), ("job_digest", "00000000000000")):
+        got = dict(want, **{field: bad})
+        r = b.whole_job_check(key, got["iters_sum"], got["failed_frames"], got["job_digest"])
+        assert r["match"] is False and r["got"][field] == bad and r["expected"][field] == want[field]
+    r = b.whole_job_check(b.job_key("TM8192", "f32", 12345, 2.0, 25, 256), 1, 2, "03")
+    assert r["match"] is None and "no committed answer" in r["note"]                          # an unknown job is neither a pass nor a failure
+    # another pool, another cap, another operating point: another job
+    assert len({b.job_key("TM8192", "f32", 4194304, e, m, p) for e in (2.0, 2.5) for m in (25, 50) for p in (256, 16)}) == 8
+    for k, v in b.EXPECTED_JOBS.items():
+        assert set(v) == {"iters_sum", "failed_frames", "job_digest"} and len(v["job_digest"]) == 14 and int(v["job_digest"], 16) < b.DIGEST_MOD, k

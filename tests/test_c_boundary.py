@@ -194,3 +194,31 @@ def test_device_resident_parts_through_one_multi_call_equal_the_one_call_job(tmp
     r = subprocess.run([exe, str(frames)] + ([str(parts)] if parts else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok:") == 2
+
+
+THREADS_SRC = os.path.join(ROOT, "tests", "c", "threads_single_frame.c")
+
+
+def test_threads_client_compiles_and_reports_no_device(tmp_path):
+    """The unchanged-perftest shape (perftest/src/main.rs:39-45: every worker loops single-frame decodes on buffers of its own)
+    from C with -Wall -Werror -pthread; without a GPU every call says `false` identically from 16 threads: exit 77."""
+    exe = build_client(tmp_path, "TM2048", src=THREADS_SRC, extra=("-pthread",))
+    if la.device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe, "16", "12"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 77, r.stdout + r.stderr
+    assert "all returned false" in r.stdout and "DIFFERENTLY" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads,trials", [(16, 54), (3, 90)])
+def test_n_threads_on_the_reference_shaped_single_frame_symbols(tmp_path, threads, trials):
+    """Round 5's review, missing #3: the reference guarantees re-entrancy (src/lib.rs:15-17) and its harness relies on it
+    (perftest/src/main.rs:39-45).  16 host threads loop labrador_ldpc_decode_ms_{f32,i8,i16,f64} / labrador_ldpc_decode_bf over
+    mixed codes on caller-owned, thread-private buffers; every result (flag, iteration count, every output byte) must equal the
+    single-threaded pass over the same trials."""
+    exe = build_client(tmp_path, "TM2048", src=THREADS_SRC, extra=("-pthread",))
+    r = subprocess.run([exe, str(threads), str(trials)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:")
+    print(r.stdout)

@@ -28,6 +28,12 @@ def _check(d, world, total):
     assert d["parity"]["mismatches"] == 0 and d["parity"]["frames_compared"] == 32 * world
     assert d["metric"].startswith("decoded codewords/sec @25 min-sum iters, TM8192")
     assert d["cpu_baseline"] is None and "configs" not in d
+    # the line verifies itself: the whole job's exact results against the committed one-GPU answers of bench.EXPECTED_JOBS
+    assert d["parity"]["whole_job"]["match"] is True, d["parity"]["whole_job"]
+    # ... and explains a slow rank by itself: device, kernel time and the clock held under load, per rank
+    assert [r["rank"] for r in d["ranks"]] == list(range(world)) and sum(r["frames"] for r in d["ranks"]) == total
+    assert all(r["kernel_ms"] > 0 and r["wall_s"] > 0 and r["device"] == 0 for r in d["ranks"])
+    assert all(1000 < r["shader_clock_mhz_under_valu_load"] < 3000 for r in d["ranks"]), d["ranks"]
 
 
 def test_eight_ranks_on_one_gpu_started_by_bench_py():
@@ -69,5 +75,33 @@ def test_an_n_gpu_job_is_the_one_gpu_job_bit_for_bit():
         d = _one_json_line(r.stdout)
         assert d["n_gpus"] == world and d["config"]["total_frames"] == total
         seen[world] = (d["diag"]["job_digest"], d["diag"]["iters_sum"], d["diag"]["failed_frames"], d["diag"]["mean_iters_returned"])
+        assert d["parity"]["whole_job"]["match"] is True, d["parity"]["whole_job"]           # against the COMMITTED constants, not only each other
     assert len(set(seen.values())) == 1, seen
     assert seen[1][1] > total * 5 and 0 <= seen[1][2] < total // 10
+
+
+@pytest.mark.parametrize("dtype,code,ebn0", [("i8", "TM8192", 2.0), ("i8", "TM5120", 4.0)])
+def test_the_i8_jobs_verify_themselves_too(dtype, code, ebn0):
+    """The bit-sliced i8 kernels behind the same self-check: 1 and 3 ranks reproduce the committed answers of the 40 961-frame jobs."""
+    for world in (1, 3):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--devices", ",".join(["0"] * world), "--code", code, "--dtype", dtype,
+                            "--ebn0", str(ebn0), "--total-frames", "40961", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-configs"],
+                           capture_output=True, text=True, cwd=ROOT, timeout=1500)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        d = _one_json_line(r.stdout)
+        assert d["parity"]["whole_job"]["match"] is True, d["parity"]["whole_job"]
+
+
+@pytest.mark.parametrize("world,frame", [(1, 30000), (3, 30000), (8, 40960)])
+def test_a_corrupted_shard_voids_the_line(world, frame):
+    """One flipped output bit in ONE frame of one rank's shard (bench.py --corrupt-frame, a test hook), outside every rank's oracle
+    sample: the whole-job digest no longer equals the committed one, the line says so, carries no value, and bench exits non-zero."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--devices", ",".join(["0"] * world), "--total-frames", "40961", "--steps", "1",
+                        "--warmup", "0", "--rank-parity-frames", "32", "--no-configs", "--corrupt-frame", str(frame)],
+                       capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode != 0, r.stdout[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["value"] is None and "whole-job" in d["error"]
+    w = d["parity"]["whole_job"]
+    assert w["match"] is False and w["got"]["job_digest"] != w["expected"]["job_digest"]
+    assert w["got"]["iters_sum"] == w["expected"]["iters_sum"] and d["parity"]["mismatches"] == 0      # only the digest sees it

@@ -120,7 +120,7 @@ def test_job_results_are_equal_for_one_and_two_ranks():
 PROBE = r'''
 import json, os, sys
 sys.path.insert(0, sys.argv[1])
-from labrador_ldpc_amd.sharding import init_ranks, reduce_max, reduce_sum, barrier, finish_ranks, shard_range
+from labrador_ldpc_amd.sharding import init_ranks, reduce_max, reduce_sum, gather, barrier, finish_ranks, shard_range
 rank, local_rank, world = init_ranks()
 if len(sys.argv) > 3 and int(sys.argv[3]) == rank:
     sys.exit(7)                                   # a failing rank, before the group's first collective
@@ -128,8 +128,9 @@ barrier()
 start, count = shard_range(int(sys.argv[2]), world, rank)
 mx = reduce_max([1.0 + rank, 10.0 - rank])
 sm = reduce_sum([count])
+per_rank = gather([float(rank), float(start), float(count)])        # bench.py's per-rank diagnostics: every rank's row, by rank
 if rank == 0:
-    print(json.dumps({"world": world, "local_rank": local_rank, "max": mx, "frames": sm[0]}), flush=True)
+    print(json.dumps({"world": world, "local_rank": local_rank, "max": mx, "frames": sm[0], "ranks": per_rank}), flush=True)
 finish_ranks()
 '''
 
@@ -147,7 +148,9 @@ def test_spawn_local_ranks_runs_one_process_per_rank(tmp_path, capfd):
     lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     got = json.loads(lines[0])
-    assert got == {"world": 2, "local_rank": 0, "max": [2.0, 10.0], "frames": 37.0}
+    assert got == {"world": 2, "local_rank": 0, "max": [2.0, 10.0], "frames": 37.0, "ranks": [[0.0, 0.0, 19.0], [1.0, 19.0, 18.0]]}
+    from labrador_ldpc_amd.sharding import gather
+    assert gather([3.0, 4.0]) == [[3.0, 4.0]]                       # without a group: this process's row alone
     # a rank that dies takes the job down with a non-zero status instead of hanging the others
     assert spawn_local_ranks([str(script), root, "37", "1"], 2, env=env, timeout=120) != 0
 
