@@ -89,11 +89,12 @@ def test_no_spill_traffic_inside_the_iteration_loops(built_objects):
     assert seen >= 100
 
 
-def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
+def test_bit_sliced_iteration_loops_carry_at_most_a_few_scratch_reloads(built_objects):
     """The bit-sliced kernels have no barrier to find their loops by; their iteration is what lies between the first and the last
-    ds_bpermute_b32 of a kernel (the lane permutations of the pi_k blocks).  The rate-4/5 instantiations are compiled at a forced 256
-    registers and report ~105 spilled registers: all of them in the prologue / epilogue (LLR transposition, output packing) -- the
-    7 000-instruction iteration must not touch scratch memory."""
+    ds_bpermute_b32 of a kernel (the lane permutations of the pi_k blocks).  The rate-2/3 loops must not touch scratch memory at all;
+    the rate-1/2 loops (three waves per SIMD, 168 registers) carry a handful of spilled values -- measured 7-9 values, 8-14 scratch
+    instructions -- and the bound below is that count plus a small margin (round 5 advice: the old name said "free of scratch", the old
+    bound was 24)."""
     import re
     import subprocess
     import tempfile
@@ -127,7 +128,7 @@ def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
         # with ~10 spills against 19.7 with none under scheduling pins and 17.6 at two waves per SIMD, profiles/r05_kbench/bs_occupancy.txt);
         # a regression that spills in earnest (68 values cost TM2048 half its rate) must still fail here.
         r12 = "ILi5E" in name or "ILi8E" in name
-        assert n <= (24 if r12 else 0), f"{name}: {n} scratch instructions inside the iteration"
+        assert n <= (16 if r12 else 0), f"{name}: {n} scratch instructions inside the iteration"
         assert sum(1 for t in loop if t.startswith("v_bitop3_b32")) > 0.6 * len(loop) - 200      # ... which is Boolean arithmetic
         seen += 1
     assert seen == 4                                       # TM1536, TM2048, TM6144, TM8192 (the rate-4/5 codes: the split kernel below)
@@ -163,3 +164,28 @@ def test_bit_sliced_iteration_loops_are_free_of_scratch_traffic(built_objects):
         waits = sum(1 for t in body if t.startswith("s_waitcnt"))
         if "ILi4E" in name or "ILi7E" in name:
             assert waits < perm, f"{name}: {waits} s_waitcnt for {perm} ds_bpermute_b32"
+
+
+def test_experiment_patches_apply_where_they_say_they_do(tmp_path):
+    """Round 5 advice: tools/experiments/*.patch are evidence only while they reproduce.  A patch applies to the working tree unless
+    its first line names the commit it was cut against (`# base: <commit>`): then it must apply to THAT tree (checked where the
+    repository's history is available -- not on the GPU box, whose snapshot has no .git)."""
+    import glob
+    import subprocess
+    pats = sorted(glob.glob(os.path.join(ROOT, "tools", "experiments", "*.patch")))
+    assert len(pats) >= 3
+    for pat in pats:
+        first = open(pat).readline()
+        if first.startswith("# base:"):
+            base = first.split(":", 1)[1].strip()
+            if not os.path.isdir(os.path.join(ROOT, ".git")):
+                continue
+            tree = tmp_path / base
+            tree.mkdir()
+            ar = subprocess.run(["git", "-C", ROOT, "archive", base], capture_output=True)
+            assert ar.returncode == 0, f"{os.path.basename(pat)}: base commit {base} not in this repository"
+            subprocess.run(["tar", "-x", "-C", str(tree)], input=ar.stdout, check=True)
+            r = subprocess.run(["git", "apply", "--check", pat], cwd=str(tree), capture_output=True, text=True)
+        else:
+            r = subprocess.run(["git", "apply", "--check", pat], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, f"{os.path.basename(pat)} does not apply: {r.stderr[-600:]}"
