@@ -186,6 +186,7 @@ template <> struct Ops<float> {                       // decoder.rs:69-77
     LDPC_DEV static float store(R x) { return x; }
     LDPC_DEV static R from_lds(float x) { return x; }                           // already canonical
     LDPC_DEV static int bits(R x) { return __float_as_int(x); }
+    static constexpr bool SIGN_WORD_IS_BIT31_ONLY = true;      // (the register-lean check phases form it from raw bits themselves)
     LDPC_DEV static int sign_word(R x) { return __float_as_int(x) & (int)0x80000000; }     // bit 31 of a message, alone
     LDPC_DEV static R add(R a, R b) { return a + b; }                           // :74
     LDPC_DEV static R sub(R a, R b) { return a - b; }                           // :75
@@ -355,6 +356,7 @@ template <> struct Ops<double> {
     LDPC_DEV static double store(R x) { return x; }
     LDPC_DEV static R from_lds(double x) { return x; }
     LDPC_DEV static int bits(R x) { return __double2hiint(x); }
+    static constexpr bool SIGN_WORD_IS_BIT31_ONLY = true;
     LDPC_DEV static int sign_word(R x) { return __double2hiint(x) & (int)0x80000000; }
     LDPC_DEV static R add(R a, R b) { return a + b; }
     LDPC_DEV static R sub(R a, R b) { return a - b; }
@@ -464,10 +466,21 @@ template <> struct Ops<int8_t>  : IntOps<int8_t, -128, 127> {};
 template <> struct Ops<int16_t> : IntOps<int16_t, -32768, 32767> {};
 
 // i32 LLRs (decoder.rs:60-68): genuine 32-bit integer arithmetic -- the f32 pipeline is exact only to 2^24.
-// Saturating add/sub are v_add_i32 / v_sub_i32 with the clamp bit, saturating_abs is max(x, 0 -sat x)
-// (|INT_MIN| = INT_MAX, :64), minima are v_min3_i32 on magnitudes computed once per message (the compiler
-// shares them).  "Negative" is bit 31, so the sign-word machinery applies unchanged.  The LDS element is a
-// 4-byte container (float) holding the integer's bits, which lets the pair kernel's 64-bit accesses carry it.
+// Saturating add/sub are v_add_i32 / v_sub_i32 with the clamp bit.  Those, every integer min / max / compare and the three-operand
+// integer forms issue at HALF the rate of v_xor / v_sub_u32 / v_ashrrev / v_bitop3 on gfx950 (tools/ubench/wide_rate.hip: 1.8 against
+// 0.95 ns per wave-instruction and SIMD), which is why decode_ms::<i32> runs at about half decode_ms::<f32>'s rate (f32 add / sub / fma
+// are full rate, |x| is a free source modifier there and the sign application one v_bitop3).  Round 6 moved what it could to
+// full-rate operations (TM8192 i32 4.24 -> see profiles/r06_final/rates_all_codes.txt):
+//   * the self-correction without a compare (self_correct below: four full-rate operations for xor + two v_cmp + s_and + select);
+//   * the MAGNITUDE as the wrapping |x| (one v_sub_u32 + one v_max_i32 instead of v_sub_i32 clamp + v_max_i32).  It wraps where
+//     saturating_abs saturates -- |INT_MIN| comes out as 0x80000000 instead of INT_MAX (:64) -- so magnitudes are compared UNSIGNED and
+//     every exclusive minimum is capped at maxval = INT_MAX (which decoder.rs:414-415 does anyway: min1 / min2 start there):
+//     min(sat|a|, ...) = min_u32(wrap|a|, INT_MAX, ...).  The cap rides in a v_min3_u32's third operand except on rows of degree 2 and
+//     4-6 (one operation more per three edges).
+//   (Sign words as x >> 31 -- which would also save the shift in apply_sign -- were measured at the compiler: 118 spilled registers
+//   in the TM8192 pair kernel against 1; not adopted.)
+// "Negative" is bit 31, so the sign-word machinery applies unchanged.  The LDS element is a 4-byte container (float) holding the
+// integer's bits, which lets the pair kernel's 64-bit accesses carry it.
 template <> struct Ops<int32_t> {
     using R = int;
     using E = float;
@@ -480,25 +493,33 @@ template <> struct Ops<int32_t> {
     LDPC_DEV static float store(R x) { return __int_as_float(x); }
     LDPC_DEV static R from_lds(float x) { return __float_as_int(x); }
     LDPC_DEV static int bits(R x) { return x; }
+    static constexpr bool SIGN_WORD_IS_BIT31_ONLY = true;
     LDPC_DEV static int sign_word(R x) { return x & (int)0x80000000; }
     LDPC_DEV static R add(R a, R b) { R d; asm("v_add_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // :65
     LDPC_DEV static R sub(R a, R b) { R d; asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // :66
     LDPC_DEV static R sub_nv(R a, R b) { return sub(a, b); }                    // (32-bit: the clamp is what keeps it from wrapping)
-    LDPC_DEV static R mag(R x) { const R n = sub(0, x); return n > x ? n : x; }  // :64
+    // |x| as an UNSIGNED word (wraps INT_MIN to 0x80000000 where :64 saturates to INT_MAX): see above
+    LDPC_DEV static R mag(R x) { const R s = x >> 31; return (R)((unsigned)(x ^ s) - (unsigned)s); }
+    LDPC_DEV static R umin(R a, R b) { return (unsigned)b < (unsigned)a ? b : a; }
     template <bool AX, bool AY>
     LDPC_DEV static R min2(R x, R y)
     {
         const R a = AX ? mag(x) : x, b = AY ? mag(y) : y;
-        return b < a ? b : a;
+        return umin(a, b);
     }
-    template <bool AX> LDPC_DEV static R min2_cap(R x) { return AX ? mag(x) : x; }          // magnitudes never exceed maxval
-    template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return min2<AX, AY>(x, y); }
+    template <bool AX> LDPC_DEV static R min2_cap(R x) { return umin(AX ? mag(x) : x, maxval()); }
+    template <bool AX, bool AY> LDPC_DEV static R min3_cap(R x, R y) { return umin(min2<AX, AY>(x, y), maxval()); }
     template <bool AX, bool AY, bool AZ>
     LDPC_DEV static R min3(R x, R y, R z) { return min2<false, AZ>(min2<AX, AY>(x, y), z); }
+    // decoder.rs:422-425: v = 0 where the old v is non-zero and of the other sign, else nv -- without a compare: bit 31 of
+    // (nv ^ old) & (old | -old) says "drop" (old | -old has bit 31 set exactly for old != 0, INT_MIN included); an arithmetic shift
+    // spreads it over the word and it is cleared out of nv: v_sub_u32, v_bitop3, v_ashrrev, v_bitop3 -- all full rate
     template <int FORM>
-    LDPC_DEV static R self_correct(R nv, R old)                                  // decoder.rs:422-425
+    LDPC_DEV static R self_correct(R nv, R old)
     {
-        return (old != 0 && ((nv ^ old) < 0)) ? 0 : nv;
+        const int negold = (int)(0u - (unsigned)old);
+        const int drop = __builtin_amdgcn_bitop3_b32(nv, old, negold, 0x2C) >> 31;          // (a ^ b) & (b | c)
+        return __builtin_amdgcn_bitop3_b32(nv, drop, drop, 0x30);                           // a & ~b
     }
     template <bool BOUNDED, int FORM = 0> LDPC_DEV static R self_correct_b(R nv, R old) { return self_correct<0>(nv, old); }
     // m >= 0 negated when the product of the other edges' signs is negative (:398-405)
@@ -1369,6 +1390,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                     par = xor_into<J1 - J0>(par, xw);
                     sgnw = xor_into<J1 - J0>(sgnw, vw);
                 });
+                static_assert(O::SIGN_WORD_IS_BIT31_ONLY, "the register-lean check phase forms sign words from raw bits");
                 const int sgn = sgnw & (int)0x80000000;
                 if constexpr (LEAN_VERDICT) sgn_row[S][Rw] = sgn;
                 else finish_row(S_, R_, sgn);
@@ -1440,6 +1462,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                             a[J] = v[S][B];
                         }
                         par ^= xw[J - J0];                                             // :445-447
+                        static_assert(O::SIGN_WORD_IS_BIT31_ONLY, "the in-place check phase forms sign words from raw bits");
                         sgn ^= O::bits(a[J]) & (int)0x80000000;                        // :439-441
                     });
                 });
