@@ -503,6 +503,36 @@ struct Decoder {
         });
     }
 
+    // the same for the lanes of `fresh` only (slot refill, decode_refill below): they start a codeword, the other lanes keep theirs
+    BS_FN void reset_state(B &b, uint64_t fresh)
+    {
+        auto z = [&](V &x) { x = B::select_lanes(fresh, B::c(0), x); };
+        const V fp = b.plane_of(fresh);
+        sfor<0, NROWS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            if constexpr (GEO::has_row(r)) {
+                sfor<0, MG>([&](auto K_) { constexpr int k = decltype(K_)::value; z(m1[r][k]); z(m2[r][k]); });
+                z(S[r]);
+                sfor<0, ARG>([&](auto K_) { z(arg[r][decltype(K_)::value]); });
+            }
+        });
+        sfor<0, NB>([&](auto E_) {
+            constexpr int e = decltype(E_)::value;
+            if constexpr (GEO::owns(e)) {
+                z(sv[e]);
+                if constexpr (GEO::nz_in_lds(e)) b.lds_write32_if(B::add(B::shl(lane, 2), B::c(GEO::nz_addr(e))), B::c(0), fp);
+                else z(nz[e]);
+            }
+        });
+        sfor<0, NCOLS>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            if constexpr (GEO::owns_col(c)) {
+                if constexpr (GEO::HARD_LDS) b.lds_write32_if(hard_addr(c), B::c(0), fp);
+                else z(hard[c]);
+            }
+        });
+    }
+
     // "this edge holds the row's min1": arg[r] == slot.  An AND over ARG literals (plane k, or its complement where bit k of SLOT is 0):
     // three literals in the first instruction, two more per further one -- the complements ride in the truth tables
     template <int R, int SLOT>
@@ -836,6 +866,9 @@ struct Decoder {
 constexpr int STAGE_BYTES = 2048 + 16 * 8;
 constexpr int stage_skew(int p) { return p + 16 * (p / 256); }
 
+template <int CODE, class B>
+BS_FN void gather_planes(B &b, typename B::V p0, int stage, typename B::V (&X)[8]);
+
 // block column c of the group's LLRs -> the lane's 8 bit planes X[p]: bit (index / L) of lane (q, index mod L) = bit p of the LLR.
 // Global side: two 16-byte loads per lane, consecutive lanes consecutive bytes (the wave reads the column's 128-byte lines whole,
 // once).  The loads are unconditional (a predicated load is an EXEC-masked branch per load): lanes of codewords beyond the batch read
@@ -845,7 +878,7 @@ BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, int c, uint3
 {
     using GEO = Geo<CODE>;
     using V = typename B::V;
-    constexpr int M = GEO::M, N = GEO::N, L = GEO::L, Q = GEO::Q, W = GEO::W, G = GEO::G;
+    constexpr int M = GEO::M, N = GEO::N, Q = GEO::Q, W = GEO::W, G = GEO::G;
     sfor<0, 2>([&](auto H_) {
         constexpr int h = decltype(H_)::value;
         const V p = B::add(B::shl(d.lane, 4), B::c(1024 * h));                               // slab position of the lane's 16 bytes
@@ -860,6 +893,21 @@ BS_FN void load_column_planes(B &b, const D &d, const int8_t *llrs, int c, uint3
     // lane (cw, q, ll) gathers the bytes of its 32 indices: q * Q + ll + L * bit; dword dd holds bits dd, 8 + dd, 16 + dd, 24 + dd
     const V cw = B::shr(d.lane, ilog2c(W));
     const V p0 = B::add(B::add(B::shl(cw, ilog2c(M)), B::shl(d.q, ilog2c(Q))), d.ll);       // position of bit 0
+    // (compiler fences around the slab's use: the 16-byte vector stores above and the byte loads below are accesses of different types
+    // to the same LDS bytes, and without the fence the NEXT use of the slab's stores were seen moved ahead of this use's loads -- round 6,
+    // place_slot's two-piece staging: all-wrong decodes on the GPU, correct in the CPU emulation)
+    B::mem_fence();
+    gather_planes<CODE>(b, p0, stage, X);
+    B::mem_fence();
+}
+
+// the 32 LLR bytes at slab positions p0 + L * bit (bit = 0 .. 31; the slab is skewed) -> the 8 bit planes X[p] of those 32 indices
+template <int CODE, class B>
+BS_FN void gather_planes(B &b, typename B::V p0, int stage, typename B::V (&X)[8])
+{
+    using GEO = Geo<CODE>;
+    using V = typename B::V;
+    constexpr int L = GEO::L;
     auto at = [&](int bit) {                                                                  // skewed LDS address of bit `bit`
         if constexpr (L * 32 <= 256 && 256 % (L * 32) == 0) {
             // the lane's 32 bytes lie inside one 256-byte run: one skew for all of them
@@ -1010,6 +1058,225 @@ BS_FN void decode_group(B &b, const int8_t *llrs_all, uint8_t *output_all, uint3
     const V first = B::and_(valid2, B::eq(lw2, B::c(0)));
     b.gstore32(iters, B::shl(cw2, 2), iters_v, first);
     b.gstore8(success, cw2, ok_v, first);
+}
+
+
+// ---- slot refill (round 6) -------------------------------------------------------------------------------------------------------
+// The reference's harness hands a worker its next frame the moment one finishes (perftest/src/main.rs:39-52).  decode_group holds all
+// G codewords of a wave until the slowest is done: 1.05-1.19 x the frames' own passes for G <= 4, 1.31 x for TM1536 (G = 8).  Here a
+// slot whose codeword is finished -- converged, or at the iteration cap -- hands in its results and takes the wave's next frame while
+// the other slots keep iterating.  Round 5 built this with whole-wave prologues / epilogues (every block column of every slot, masked)
+// and lost: an event cost half an iteration (profiles/r05_kbench/slot_refill.txt).  Here an event is PER SLOT and COOPERATIVE: all 64
+// lanes work on the one codeword that leaves (its NCOLS x W output dwords, one per lane) and on the one that arrives (its N LLR bytes
+// through the staging slab, then one (block column, lane) unit of 32 LLRs per lane: the byte gather and the 8 x 8 bit transposes run
+// once per slot instead of once per block column), and only the state RESET touches every state register (one v_cndmask each).
+// Frames are wave-uniform scalars, so a slot's global addresses are a scalar base plus a lane offset whatever the batch size.
+template <int G, int W>
+struct Slots {
+    static constexpr uint64_t gm(int g) { return (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1)) << ((g * W) & 63); }      // the lanes of slot g
+    uint64_t active = 0;                   // lanes of the slots with a codeword in progress
+    uint64_t fin = ~0ull, ok = 0;          // lanes of the slots that are finished (initially: all are to be filled); of those, the successes
+    uint32_t it[G], fr[G];                 // iterations done, frame per slot
+    BS_FN void start() { active = 0; fin = ~0ull; ok = 0; sfor<0, G>([&](auto G_) { it[decltype(G_)::value] = 0; fr[decltype(G_)::value] = 0; }); }
+    // slots at the iteration cap are finished as they are: (false, max_iters)  (decoder.rs:466-474; max_iters = 0: at once).
+    // Branch-free, like verdict(): these run inside the iteration loop, where scalar branches cut the loop body into blocks across
+    // which the compiler keeps 70 more values live (round 5)
+    BS_FN void expire(uint32_t maxiters)
+    {
+        sfor<0, G>([&](auto G_) { constexpr int g = decltype(G_)::value; fin |= ((active & gm(g)) != 0 && it[g] >= maxiters) ? gm(g) : 0ull; });
+    }
+    // after an iteration: a slot whose checks all hold is finished with (true, its iteration index)  (:453-463); the others count on
+    BS_FN void verdict(uint64_t unsat_lanes)
+    {
+        sfor<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            const bool act = (active & gm(g)) != 0, sat = (unsat_lanes & gm(g)) == 0;
+            const uint64_t won = (act && sat) ? gm(g) : 0ull;
+            fin |= won;
+            ok |= won;
+            it[g] += (act && !sat) ? 1u : 0u;
+        });
+    }
+};
+
+// the finished codeword of the slot whose first lane is `first`: its hard-decision words (LDS, one per block column and lane) -> the
+// NCOLS x W dwords of its output, MSB first inside each byte (decoder.rs:455-461 / :467-473), one dword per lane and round
+template <int CODE, class B, class D>
+BS_FN void emit_slot(B &b, const D &d, int first, uint8_t *out, uint32_t *iters_p, uint8_t *ok_p, uint32_t iters_v, uint32_t ok_v)
+{
+    using GEO = Geo<CODE>;
+    using V = typename B::V;
+    constexpr int M = GEO::M, L = GEO::L, W = GEO::W, NCOLS = GEO::NCOLS, UNITS = NCOLS * W;
+    sfor<0, (UNITS + 63) / 64>([&](auto R_) {
+        constexpr int r = decltype(R_)::value;
+        const V u = B::add(d.lane, B::c(64 * r));
+        const V valid = B::less_u(u, B::c(UNITS));
+        const V c = B::and_(B::shr(u, ilog2c(W)), valid);                      // block column (0 for the idle lanes of the last round)
+        const V lw = B::and_(u, B::c(W - 1));                                     // lane of the codeword
+        const V b0 = B::shl(B::and_(lw, B::c(L - 1)), 5 - ilog2c(L));            // first bit of this unit's 32 indices: 32 ll / L
+        const V qbase = B::add(B::shl(c, 8), B::shl(B::add(B::c(first), B::and_(lw, B::c(~(L - 1) & (W - 1)))), 2));   // column's words, quarter's first lane
+        V o = B::c(0);
+        sfor<0, L>([&](auto LL_) {
+            constexpr int l2 = decltype(LL_)::value;
+            const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(GEO::LDS_HARD + 4 * l2))), b0);
+            sfor<0, 32 / L>([&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                constexpr int t = l2 + L * k;
+                constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
+                o = B::or_(o, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
+            });
+        });
+        const V off = B::add(B::mul_u(c, (uint32_t)(M / 8)), B::shl(lw, 2));
+        if constexpr (GEO::HARD_LDS) b.gstore32_stream(out, off, o, valid);
+        else b.gstore32(out, off, o, valid);
+    });
+    const V first_lane = B::eq(d.lane, B::c(0));
+    b.gstore32(iters_p, B::c(0), B::c(iters_v), first_lane);
+    b.gstore8(ok_p, B::c(0), B::c(ok_v), first_lane);
+}
+
+// a fresh codeword for the slot whose first lane is `first`: its N LLR bytes -> staging slab (16 bytes per lane and round, whole
+// lines) -> per lane ONE unit (block column c, codeword lane lw) of 32 LLRs -> its 8 bit planes, written to that lane's plane words.
+// The slab is the hard-decision words' area; where the "v != 0" planes of the ACTIVE slots live behind those words (Geo::NZ_IN_SLAB:
+// rate 1/2) only the words' own NCOLS x 256 bytes are free, and the codeword passes through in pieces of 1024 bytes.
+template <int CODE> struct SlotLoad {
+    using GEO = Geo<CODE>;
+    static constexpr int M = GEO::M, N = GEO::N, W = GEO::W;
+    static constexpr int SLAB_FREE = GEO::NZ_IN_SLAB > 0 ? GEO::NCOLS * 256 : GEO::HARD_BYTES;
+#ifdef BS_REFILL_PIECE
+    static constexpr int PIECE = (N % BS_REFILL_PIECE == 0 && BS_REFILL_PIECE % M == 0) ? BS_REFILL_PIECE : N;
+#else
+    static constexpr int PIECE = (N + 16 * (N / 256) <= SLAB_FREE) ? N : 1024;      // bytes staged at a time
+#endif
+    static_assert(PIECE % M == 0 && N % PIECE == 0 && PIECE % 16 == 0 && PIECE + 16 * (PIECE / 256) <= SLAB_FREE, "a piece is whole block columns and fits the slab");
+    static constexpr int COLS = PIECE / M, UNITS = COLS * W;                         // block columns and (column, lane) units per piece
+    static constexpr int ROUNDS = (PIECE + 1023) / 1024, PIECES = N / PIECE;        // 16-byte loads per lane and piece; pieces
+    // position inside the piece of the lane's 16 bytes of round r (the last round's idle lanes repeat the piece's last 16 bytes)
+    template <int R, class B> static BS_FN typename B::V pos(typename B::V lane)
+    {
+        using V = typename B::V;
+        V p = B::add(B::shl(lane, 4), B::c(1024 * R));
+        if constexpr (1024 * (R + 1) > PIECE) {
+            const V over = B::less_u(B::c(PIECE - 16), p);
+            p = B::template bitop3<TT_MUX>(over, B::c(PIECE - 16), p);
+        }
+        return p;
+    }
+};
+
+// the N LLR bytes of a frame into registers: 16 bytes per lane, round and piece (whole lines, once).  Issued one frame AHEAD of
+// their use (decode_refill): an event then finds its codeword's bytes arrived long ago instead of waiting an HBM round trip.
+template <int CODE, class B, class D>
+BS_FN void fetch_slot(B &b, const D &d, const int8_t *src, typename B::V (&w)[SlotLoad<CODE>::PIECES][SlotLoad<CODE>::ROUNDS][4])
+{
+    using SL = SlotLoad<CODE>;
+    sfor<0, SL::PIECES>([&](auto P_) {
+        constexpr int piece = decltype(P_)::value;
+        sfor<0, SL::ROUNDS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            b.gload128(src, B::add(SL::template pos<r, B>(d.lane), B::c(piece * SL::PIECE)), w[piece][r]);
+        });
+    });
+}
+
+template <int CODE, class B, class D>
+BS_FN void place_slot(B &b, const D &d, int first, const typename B::V (&w)[SlotLoad<CODE>::PIECES][SlotLoad<CODE>::ROUNDS][4])
+{
+    using GEO = Geo<CODE>;
+    using SL = SlotLoad<CODE>;
+    using V = typename B::V;
+    constexpr int M = GEO::M, L = GEO::L, Q = GEO::Q, W = GEO::W, COLS = SL::COLS, UNITS = SL::UNITS;
+    sfor<0, SL::PIECES>([&](auto P_) {
+        constexpr int piece = decltype(P_)::value;
+        sfor<0, SL::ROUNDS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            const V p = SL::template pos<r, B>(d.lane);
+            b.lds_write128(B::add(B::add(p, B::shl(B::shr(p, 8), 4)), B::c(GEO::LDS_STAGE)), w[piece][r]);       // stage_skew(p)
+        });
+        B::mem_fence();            // (the slab's vector stores and byte loads: see load_column_planes)
+        sfor<0, (UNITS + 63) / 64>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            const V u = B::add(d.lane, B::c(64 * r));
+            const V valid = B::less_u(u, B::c(UNITS));
+            const V cl = B::and_(B::shr(u, ilog2c(W)), valid);                        // block column inside the piece
+            const V lw = B::and_(u, B::c(W - 1));
+            // slab position of bit 0 of unit (cl, q, ll): cl * M + q * Q + ll
+            const V p0 = B::add(B::add(B::shl(cl, ilog2c(M)), B::shl(B::shr(lw, ilog2c(L)), ilog2c(Q))), B::and_(lw, B::c(L - 1)));
+            V X[8];
+            gather_planes<CODE>(b, p0, GEO::LDS_STAGE, X);
+            const V at = B::add(B::mul_u(B::add(cl, B::c(piece * COLS)), (uint32_t)(LLRP * 256)), B::shl(B::add(B::c(first), lw), 2));
+            sfor<0, 8>([&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                b.lds_write32_if(B::add(at, B::c(GEO::LDS_LLR + k * 256)), X[k], valid);
+            });
+        });
+        B::mem_fence();
+    });
+}
+
+// ---- driver: one wave decodes frame after frame, G at a time, a finished slot taking the next frame `next()` hands out (a frame index,
+// or NO_FRAME once the supply is exhausted: the slots then drain).  llrs [batch][N] i8, output [batch][NP/8] MSB first, iters, success.
+constexpr uint32_t NO_FRAME = 0xFFFFFFFFu;
+template <int CODE, class B, class NEXT>
+BS_FN void decode_refill(B &b, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, uint32_t maxiters, NEXT next)
+{
+    using GEO = Geo<CODE>;
+    using V = typename B::V;
+    constexpr int W = GEO::W, G = GEO::G, NCOLS = GEO::NCOLS;
+    static_assert(!GEO::SPLIT && G >= 2, "slot refill: the one-wave kernels with several codewords per wave");
+    Decoder<CODE, B> d;
+    d.init_lane(b);
+    d.prime_perm(b);
+    Slots<G, W> s;
+    s.start();
+    d.reset_state(b);
+    // one frame of look-ahead: its LLR bytes are requested when its predecessor is placed and sit in registers until a slot is free
+    V ahead[SlotLoad<CODE>::PIECES][SlotLoad<CODE>::ROUNDS][4];
+    uint32_t ahead_frame = next();
+    if (ahead_frame != NO_FRAME) fetch_slot<CODE>(b, d, llrs + (size_t)ahead_frame * GEO::N, ahead);
+    // Two loops: the outer one runs once per EVENT -- some slots finished --, the inner one is the iteration loop proper, with nothing
+    // of the refill inside it (one loop with the refill as a branch cost the register allocation of the hot path dearly: round 5).
+    for (;;) {
+        d.reinit_lane();       // (lane constants formed here, from an opaque copy of the lane index: as common subexpressions of an earlier
+                               // block's they would hold registers through the iterations)
+        const uint64_t done = s.fin & s.active;
+        if constexpr (!GEO::HARD_LDS)
+            if (done) sfor<0, NCOLS>([&](auto C_) { constexpr int c = decltype(C_)::value; b.lds_write32(d.hard_addr(c), d.hard[c]); });
+        uint64_t fresh = 0;
+        sfor<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            constexpr uint64_t gm = Slots<G, W>::gm(g);
+            if (s.fin & gm) {
+                if (s.active & gm) {
+                    const size_t f = s.fr[g];
+                    emit_slot<CODE>(b, d, g * W, output + f * GEO::OUT_LEN, iters + f, success + f, s.it[g], (s.ok & gm) ? 1u : 0u);
+                }
+                s.active &= ~gm;
+            }
+        });
+        // (the arrivals after ALL departures: the staging slab is the hard-decision words' area)
+        sfor<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            constexpr uint64_t gm = Slots<G, W>::gm(g);
+            if ((s.fin & gm) && ahead_frame != NO_FRAME) {
+                place_slot<CODE>(b, d, g * W, ahead);
+                s.fr[g] = ahead_frame; s.it[g] = 0; s.active |= gm; fresh |= gm;
+                ahead_frame = next();
+                if (ahead_frame != NO_FRAME) fetch_slot<CODE>(b, d, llrs + (size_t)ahead_frame * GEO::N, ahead);
+            }
+        });
+        if (fresh) d.reset_state(b, fresh);    // (after the LLRs: the hard-decision words alias the staging slab)
+        s.fin = 0; s.ok = 0;
+        s.expire(maxiters);                    // (max_iters = 0: the fresh slots are at the cap already)
+        if (s.fin) continue;
+        if (!s.active) break;
+        // ---- iterations of every slot (decoder.rs:380-464) until one of them finishes; lanes of empty slots compute on whatever they hold ----
+        do {
+            const V fail = d.iteration(b, ~s.active);
+            s.verdict(b.ballot(fail));
+            s.expire(maxiters);
+        } while (!s.fin);
+    }
 }
 
 }  // namespace bs

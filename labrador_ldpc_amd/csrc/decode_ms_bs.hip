@@ -13,6 +13,7 @@
 // worth +2 % on the two-wave kernels and +0.5 % on rate 2/3 but costs the rate-1/2 kernels (168 registers, spilling) 2.5 %
 // (profiles/r05_kbench/permute_pipeline.txt, section 7).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 
 #ifndef BS_TU
@@ -43,6 +44,36 @@ decode_ms_bs_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ outpu
     HipBackend b{lds};
     init_kernel<CODE, HipBackend>(b);
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) decode_group<CODE, HipBackend>(b, llrs, output, iters, success, batch, maxiters, g);
+}
+
+// ---- slot refill (decode_refill, decode_ms_bitslice.hpp): persistent waves, frames handed out in chunks through the launch's queue word
+// (one relaxed atomic per CHUNK frames; the word is zero between launches: every wave draws until its first ticket beyond the last chunk,
+// and the holder of the very last ticket puts the word back).  A finished slot takes the wave's next frame at once.
+template <int CODE>
+__global__ void __launch_bounds__(64, waves_per_simd<CODE>())
+decode_ms_bs_refill_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters,
+                           uint8_t *__restrict__ success, uint32_t batch, uint32_t maxiters, uint32_t *queue, uint32_t chunk)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Geo<CODE>::LDS_BYTES];
+    HipBackend b{lds};
+    init_kernel<CODE, HipBackend>(b);
+    const uint32_t nchunks = (batch + chunk - 1) / chunk;
+    uint32_t cur = 0, end = 0;
+    auto next = [&]() -> uint32_t {
+        if (cur == end) {
+            uint32_t t = 0;
+            if (threadIdx.x == 0) t = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t >= nchunks) {                                                     // (decode_refill asks no more after this)
+                if (t == nchunks + gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return NO_FRAME;
+            }
+            cur = t * chunk;
+            end = batch - cur < chunk ? batch : cur + chunk;
+        }
+        return cur++;
+    };
+    decode_refill<CODE, HipBackend>(b, llrs, output, iters, success, maxiters, next);
 }
 
 // ---- the rate-4/5 codes: a group of codewords shared by the two waves of a workgroup (decode_ms_bitslice_split.hpp).  One group per
@@ -81,6 +112,36 @@ hipError_t launch_split(const int8_t *llrs, uint8_t *output, uint32_t *iters, ui
     return hipGetLastError();
 }
 
+uint32_t *bs_queue_word(hipStream_t stream);          // decode_ms_i8.hip: the launch queue's word of (device, stream), or nullptr (claim_counter)
+
+template <int CODE>
+hipError_t launch_refill(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream,
+                         uint32_t *queue)
+{
+    constexpr int G = Geo<CODE>::G;
+    if (batch == 0) return hipSuccess;
+    if (batch > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    static std::atomic<int> cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int resident = cached[dev].load(std::memory_order_relaxed);
+    if (resident == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_bs_refill_kernel<CODE>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = per_cu * cus;
+        cached[dev].store(resident, std::memory_order_relaxed);
+    }
+    // frames per draw: 8 rounds of slots, fewer for short launches (at least ~4 draws per resident wave)
+    size_t chunk = 8 * (size_t)G;
+    while (chunk > (size_t)G && batch / chunk < 4 * (size_t)resident) chunk /= 2;
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    const size_t grid = nchunks < (size_t)resident ? nchunks : (size_t)resident;
+    hipLaunchKernelGGL((decode_ms_bs_refill_kernel<CODE>), dim3((unsigned)grid), dim3(64), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
+                       queue, (uint32_t)chunk);
+    return hipGetLastError();
+}
+
 template <int CODE>
 hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
 {
@@ -98,15 +159,19 @@ hipError_t launch(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t 
 
 // i8 LLRs through the bit-sliced kernel; hipErrorInvalidConfiguration for the codes it is not built for (the TC codes: their
 // circulants are not quarter-wise rotations).  llrs 4-byte aligned, output 4-byte aligned (the caller checks).  Rate 4/5: two waves per group.
+// refill: 1 = slot refill where the code has it (bitslice_refills()), 0 = the lockstep kernels
 hipError_t launch_decode_ms_bitsliced_unit2(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                            uint32_t maxiters, hipStream_t stream);
+                                            uint32_t maxiters, hipStream_t stream, int refill);
 #if BS_TU == 2
 hipError_t launch_decode_ms_bitsliced_unit2(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                            uint32_t maxiters, hipStream_t stream)
+                                            uint32_t maxiters, hipStream_t stream, int refill)
 {
+    uint32_t *queue = refill ? bs::bs_queue_word(stream) : nullptr;
     switch (code) {
         case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
-        case TM1536: return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM1536:
+            if (queue) return bs::launch_refill<TM1536>(llrs, output, iters, success, batch, maxiters, stream, queue);
+            return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
         case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
         case TM6144: return bs::launch<TM6144>(llrs, output, iters, success, batch, maxiters, stream);
         default: return hipErrorInvalidConfiguration;
@@ -114,13 +179,24 @@ hipError_t launch_decode_ms_bitsliced_unit2(int code, const int8_t *llrs, uint8_
 }
 #else
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                      uint32_t maxiters, hipStream_t stream)
+                                      uint32_t maxiters, hipStream_t stream, int refill)
 {
+    // (slot refill on TM2048, G = 4: built, bit-exact, -1 ... -4 %: its codeword passes the staging slab in two pieces -- the "v != 0"
+    // planes of the active slots live behind the hard-decision words -- and four slots lose little to the lockstep:
+    // profiles/r06_kbench/slot_refill_r06.txt.  -DBS_REFILL_R12=1 builds it.)
+#ifndef BS_REFILL_R12
+#define BS_REFILL_R12 0
+#endif
     switch (code) {
-        case TM2048: return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM2048:
+#if BS_PLANES == 8 && BS_REFILL_R12
+            if (uint32_t *queue = refill ? bs::bs_queue_word(stream) : nullptr)
+                return bs::launch_refill<TM2048>(llrs, output, iters, success, batch, maxiters, stream, queue);
+#endif
+            return bs::launch<TM2048>(llrs, output, iters, success, batch, maxiters, stream);
         case TM8192: return bs::launch<TM8192>(llrs, output, iters, success, batch, maxiters, stream);
 #if BS_PLANES == 8
-        default: return launch_decode_ms_bitsliced_unit2(code, llrs, output, iters, success, batch, maxiters, stream);
+        default: return launch_decode_ms_bitsliced_unit2(code, llrs, output, iters, success, batch, maxiters, stream, refill);
 #else                   // (a 16-plane experiment build, tools/bs_alt_build.sh -DBS_PLANES=16, carries the rate-1/2 codes only)
         default: return hipErrorInvalidConfiguration;
 #endif

@@ -21,7 +21,9 @@ namespace ldpc {
 // thousand groups in flight to fill the chip and takes ~3x as long per codeword as a whole workgroup of the f32-pipe kernels: small
 // batches are faster on those (and a single frame's latency is theirs).  `variant` 1 / 2 / 32 still name the f32-pipe kernels explicitly.
 hipError_t launch_decode_ms_bitsliced(int code, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch,
-                                      uint32_t maxiters, hipStream_t stream);
+                                      uint32_t maxiters, hipStream_t stream, int refill);
+// the launch queue's word for the bit-sliced refill kernels (decode_ms_bs.hip does not see decode_ms_launch.hpp)
+namespace bs { uint32_t *bs_queue_word(hipStream_t stream) { return claim_counter(stream); } }
 constexpr int VARIANT_BITSLICE = 64;
 // groups of 64 / (M/32) codewords from which the bit-sliced kernel is faster per call (tools/bs_crossover.py,
 // profiles/r05_kbench/bs_crossover.txt: TM8192 and TM1280 cross at 1024 groups, TM6144 and TM5120 at 768, TM2048 and TM1536 at 2048)
@@ -64,7 +66,8 @@ const char *decode_ms_i8_kernel_name(int code, int variant, size_t batch)
     if (!valid_code(code) || variant < 0) return "";
     LDPC_SPLIT_VARIANT();
     switch (pick_i8_kernel(code, variant, lflags, batch, true)) {
-        case I8Kernel::BITSLICED:       return "decode_ms_bs_kernel";
+        // (TM1536: the slot-refill kernel unless the fixed distribution is asked for -- and on streams without a queue word)
+        case I8Kernel::BITSLICED:       return (code == TM1536 && !(lflags & LF_STATIC)) ? "decode_ms_bs_refill_kernel" : "decode_ms_bs_kernel";
         case I8Kernel::BITSLICED_SPLIT: return "decode_ms_bs_split_kernel";
         case I8Kernel::PAIR:            return "decode_ms_pair_kernel";
         case I8Kernel::PIPE:            return "decode_ms_kernel";
@@ -81,7 +84,7 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
     switch (pick_i8_kernel(code, variant, lflags, batch, bitslice_aligned(llrs, output))) {
         case I8Kernel::BITSLICED:
         case I8Kernel::BITSLICED_SPLIT:
-            return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream);
+            return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream, (lflags & LF_STATIC) ? 0 : 1);
         case I8Kernel::PAIR:           // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
             return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);
         case I8Kernel::PIPE:

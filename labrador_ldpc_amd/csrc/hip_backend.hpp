@@ -17,6 +17,7 @@ struct HipBackend {
     char *lds;
 
     static BS_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
+    static BS_FN void mem_fence() { asm volatile("" ::: "memory"); }      // no memory access of this thread moves across (compiler only)
     static BS_FN void lds_wait() { __builtin_amdgcn_s_waitcnt(0xC07F); }   // s_waitcnt lgkmcnt(0): every LDS result of this wave is in its register
     static BS_FN void pin(V &x) { asm volatile("" : "+v"(x)); }          // the value exists in a register HERE (see the iteration)
     static BS_FN V c(uint32_t x) { return x; }

@@ -39,6 +39,7 @@ struct EmuBackend {
 
     static void fence() {}
     static void lds_wait() {}
+    static void mem_fence() {}
     static void pin(V &) {}
     static V c(uint32_t x) { V r; for (auto &e : r.l) e = x; return r; }
     V lane() const { V r; for (int i = 0; i < 64; ++i) r.l[i] = (uint32_t)i; return r; }
@@ -114,6 +115,22 @@ int run(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t b
     return 0;
 }
 
+// slot refill (decode_refill): ONE emulated wave takes the whole batch, frame after frame, a finished slot taking the next frame
+template <int CODE>
+int run_refill(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    using GEO = ldpc::bs::Geo<CODE>;
+    if constexpr (GEO::SPLIT || GEO::G < 2 || GEO::TWO_WAVES) return -1;
+    else {
+        EmuBackend b(GEO::LDS_BYTES);
+        ldpc::bs::init_kernel<CODE, EmuBackend>(b);
+        uint32_t nextf = 0;
+        ldpc::bs::decode_refill<CODE, EmuBackend>(b, llrs, out, iters, ok, maxiters,
+                                                  [&]() -> uint32_t { return nextf < batch ? nextf++ : ldpc::bs::NO_FRAME; });
+        return 0;
+    }
+}
+
 // the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp): the two halves of a group run stage by stage,
 // alternately, on one shared LDS store -- the order the workgroup barriers enforce on the GPU
 template <int CODE>
@@ -172,6 +189,10 @@ extern "C" int bs_emu_decode_split(const int8_t *llrs, uint8_t *out, uint32_t *i
 {
     if constexpr (ldpc::bs::Geo<ldpc::EMU_CODE>::TWO_WAVES) return run_split<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
     else return -1;                                                     // rate 4/5 only
+}
+extern "C" int bs_emu_decode_refill(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    return run_refill<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
 }
 extern "C" int bs_emu_group(void) { return ldpc::bs::Geo<ldpc::EMU_CODE>::G; }
 extern "C" int bs_emu_code(void) { return ldpc::EMU_CODE; }

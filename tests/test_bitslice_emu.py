@@ -42,16 +42,18 @@ def emu():
         L.bs_emu_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         L.bs_emu_decode_bf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         L.bs_emu_decode_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        L.bs_emu_decode_refill.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         assert L.bs_emu_code() == oracle.CODES.index(name)
         loaded[oracle.CODES.index(name)] = L
 
-    def decode(code, llrs, maxiters, split=False):
-        """split: the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp), its two halves run alternately"""
+    def decode(code, llrs, maxiters, split=False, refill=False):
+        """split: the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp), its two halves run alternately;
+        refill: the slot-refill driver (decode_refill): ONE emulated wave takes the whole batch, a finished slot the next frame"""
         llrs = np.ascontiguousarray(llrs, dtype=np.int8)
         B = llrs.shape[0]
         out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
         it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
-        fn = loaded[code].bs_emu_decode_split if split else loaded[code].bs_emu_decode
+        fn = loaded[code].bs_emu_decode_refill if refill else loaded[code].bs_emu_decode_split if split else loaded[code].bs_emu_decode
         assert fn(llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
         return out, it, ok
     def decode_bf(code, hard, maxiters):
@@ -66,8 +68,8 @@ def emu():
     return decode
 
 
-def _same(emu, code, llrs, maxiters, split=False):
-    o, i, k = emu(code, llrs, maxiters, split)
+def _same(emu, code, llrs, maxiters, split=False, refill=False):
+    o, i, k = emu(code, llrs, maxiters, split, refill)
     oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs, maxiters)
     bad = np.nonzero((o != oc).any(axis=1) | (i != ic) | (k != kc))[0]
     assert bad.size == 0, f"frames {bad.tolist()[:8]} differ (iters {i[bad][:8].tolist()} vs {ic[bad][:8].tolist()})"
@@ -105,6 +107,30 @@ def test_emulated_two_wave_kernel_equals_the_oracle(emu, name):
                        rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)])
     for maxiters in (25, 1, 2):
         _same(emu, code, corner, maxiters, split=True)
+
+
+@pytest.mark.parametrize("name", ["TM1536", "TM2048", "TM6144"])
+def test_emulated_slot_refill_equals_the_oracle(emu, name):
+    """Slot refill (decode_refill, round 6): a slot whose codeword is finished hands in its results and takes the wave's next frame
+    while the other slots iterate.  Frames that finish after 3 ... 25 iterations, frames that never do and saturating ones, shuffled, so
+    that slots finish in every order; batches smaller than a wave's slots; every iteration cap that makes fresh slots expire at once or
+    in step.  Pins: the cooperative per-slot prologue (one (block column, lane) unit per lane; TM2048: the codeword passes the staging
+    slab in two pieces, behind the "v != 0" planes of the active slots) and epilogue, the masked state reset, the look-ahead frame."""
+    code = oracle.CODES.index(name)
+    rng = np.random.default_rng(900 + code)
+    G = emu.group(code)
+    parts = [oracle.awgn_llrs(code, rng, f, e, np.int8, scale=s, lim=l)[0] for e, s, l, f in
+             ((2.5, 8.0, 31, 3 * G + 1), (1.0, 30.0, 127, 3), (4.5, 16.0, 127, G + 2), (2.0, 8.0, 31, G))]
+    llrs = np.concatenate(parts)
+    rng.shuffle(llrs)
+    for frames in (llrs.shape[0], 1, max(1, G - 1)):
+        for maxiters in (0, 1, 2, 7, 25):
+            it, ok = _same(emu, code, llrs[:frames], maxiters, refill=True)
+    N = llrs.shape[1]
+    corner = np.stack([np.zeros(N, np.int8), np.full(N, -128, np.int8), np.full(N, 127, np.int8), rng.integers(-128, 128, N).astype(np.int8),
+                       rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)])
+    for maxiters in (25, 1):
+        _same(emu, code, corner, maxiters, refill=True)
 
 
 @pytest.mark.parametrize("name", ["TM2048", "TM8192"])

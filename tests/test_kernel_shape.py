@@ -132,6 +132,21 @@ def test_bit_sliced_iteration_loops_carry_at_most_a_few_scratch_reloads(built_ob
         assert sum(1 for t in loop if t.startswith("v_bitop3_b32")) > 0.6 * len(loop) - 200      # ... which is Boolean arithmetic
         seen += 1
     assert seen == 4                                       # TM1536, TM2048, TM6144, TM8192 (the rate-4/5 codes: the split kernel below)
+    # the slot-refill kernel (TM1536's default, round 6): the refill lives in an OUTER loop -- per-slot epilogue, prologue, masked reset --
+    # and must not cost the iteration loop anything: no scratch traffic anywhere, the same one-wait-per-job schedule, no global access
+    # between the first and the last lane permutation of the iteration
+    seen = 0
+    for name, body in kernels.items():
+        if "decode_ms_bs_refill_kernel" not in name:
+            continue
+        assert not any(t.startswith("scratch_") for t in body), name
+        perm = [i for i, t in enumerate(body) if t.startswith("ds_bpermute_b32")]
+        assert len(perm) >= 100, name
+        loop = body[perm[0]:perm[-1]]
+        assert not any(t.startswith(("global_", "buffer_", "flat_")) for t in loop), name
+        assert sum(1 for t in loop if t.startswith("v_bitop3_b32")) > 0.6 * len(loop) - 200
+        seen += 1
+    assert seen == 1                                       # TM1536
     # the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp): no scratch memory ANYWHERE (its state fits
     # the registers: nothing is spilled, prologue and epilogue included), no global access inside the iterations (the LLR planes live in
     # LDS), and exactly two workgroup barriers per iteration and wave

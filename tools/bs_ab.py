@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from labrador_ldpc_amd import LDPCCode
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-want = sys.argv[2:]
+want = [a for a in sys.argv[2:] if not a.startswith("variant=")]
+VARIANT = ([int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("variant=")] or [64])[0]   # 64 | 256 = the lockstep kernels (no slot refill)
 dev = torch.device("cuda", 0)
 CASES = (("TM8192", 2.0), ("TM2048", 2.0), ("TM2048", 2.5), ("TM6144", 3.0), ("TM1536", 3.0), ("TM5120", 4.0), ("TM5120", 2.0), ("TM1280", 4.0))
-print("library:", os.environ.get("LABRADOR_LDPC_HIP_LIB", "(default)"), flush=True)
+print("library:", os.environ.get("LABRADOR_LDPC_HIP_LIB", "(default)"), "variant", VARIANT, flush=True)
 for name, ebn0 in CASES:
     if want and name not in want:
         continue
@@ -20,14 +21,14 @@ for name, ebn0 in CASES:
     sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (ebn0 / 10.0))))
     fr = frames * 8192 // code.n()
     llrs8 = code.awgn_frames(torch.from_numpy(pool).to(dev), fr, sigma, seed=5, dtype="i8")
-    out = code.decode_ms_batch(llrs8, 25, variant=64)
+    out = code.decode_ms_batch(llrs8, 25, variant=VARIANT)
     torch.cuda.synchronize()
     best = 1e9
     for rep in range(3):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(3):
-            out = code.decode_ms_batch(llrs8, 25, variant=64)
+            out = code.decode_ms_batch(llrs8, 25, variant=VARIANT)
         b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / 3)
     h = hashlib.sha256()
