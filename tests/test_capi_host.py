@@ -142,7 +142,7 @@ def test_abi_version_and_growable_opts_struct():
     rest as zero, so a caller that knows fewer fields cannot hand it padding as n_devices / devices."""
     import ctypes
     assert la.lib.labrador_ldpc_hip_abi_version() == 3
-    assert "0.5.0" in la.lib.labrador_ldpc_hip_version().decode()
+    assert "0.6.0" in la.lib.labrador_ldpc_hip_version().decode()
     assert ctypes.sizeof(la.HipOpts) == 40 and la.HipOpts.device.offset == 8 and la.HipOpts.n_devices.offset == 28
     code = LDPCCode.TC128
     llrs = np.ones((2, code.n()), dtype=np.float32)

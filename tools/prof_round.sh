@@ -3,7 +3,7 @@
 # rocprofv3 --kernel-trace --stats, and PMC passes (separate runs, --pmc only) for the headline kernel and for the
 # other BASELINE configs.   usage:  bash tools/prof_round.sh r03_final     -> gpurun_out/r03_final
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03_final}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r06_final}; mkdir -p $O
 rm -rf $O/trace $O/*.pmc[1-5]          # a re-run must not leave an older run's files beside the new ones
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
