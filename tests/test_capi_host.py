@@ -185,3 +185,16 @@ def test_single_frame_calls_define_their_outputs_when_the_library_cannot_run():
     ok = la.lib.labrador_ldpc_decode_bf(int(code), np.zeros(code.n() // 8, dtype=np.uint8).ctypes.data, out.ctypes.data, None, 20,
                                         ctypes.byref(iters))
     assert not ok and iters.value == 20 and not out.any()
+
+
+def test_shader_clock_probe_argument_checks_and_no_device_path():
+    """labrador_ldpc_hip_shader_clock_mhz (round 6: the per-rank clock of a bench line): NULL result pointer -> EINVAL; without a GPU
+    -> ENODEV with the reason in last_error(), nothing written; with one: a plausible gfx950 shader clock."""
+    import ctypes
+    assert la.lib.labrador_ldpc_hip_shader_clock_mhz(0, 1.0, None) == -1 and "NULL" in la.last_error()
+    mhz = ctypes.c_double(-1.0)
+    st = la.lib.labrador_ldpc_hip_shader_clock_mhz(0, 1.0, ctypes.byref(mhz))
+    if la.device_count() == 0:
+        assert st == -2 and mhz.value == -1.0 and "no HIP device" in la.last_error()
+    else:
+        assert st == 0 and 1000.0 < mhz.value < 3000.0
