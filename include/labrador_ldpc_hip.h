@@ -270,7 +270,7 @@ enum labrador_ldpc_hip_variant {
     LABRADOR_LDPC_HIP_VARIANT_F64_WORKSPACE = 100,  /* f64: the general kernel with its messages in a device workspace */
     /* flags */
     LABRADOR_LDPC_HIP_VARIANT_STATIC        = 256,  /* fixed-stride distribution of the codewords instead of the launch's queue; with
-                                                       BITSLICE: the lockstep kernel instead of the slot-refill one (TM1536) */
+                                                       BITSLICE: the lockstep kernel instead of the slot-refill one (TM1536, TM1280) */
     LABRADOR_LDPC_HIP_VARIANT_NAN_ONE_PASS  = 512,  /* TM5120 / TM1280 f32: NaN LLRs handled inside the one kernel ... */
     LABRADOR_LDPC_HIP_VARIANT_NAN_TWO_PASS  = 1024  /* ... or by a second launch over marked codewords (the default from ~1000 frames) */
 };
@@ -441,7 +441,7 @@ const char *labrador_ldpc_hip_version(void);
 const char *labrador_ldpc_hip_build_id(void);
 
 /* Name of the kernel labrador_ldpc_decode_ms_batch_i8 launches for a 4-byte-aligned device batch of `batch` frames with this
- * `variant` ("decode_ms_bs_kernel" / "decode_ms_bs_refill_kernel" / "decode_ms_bs_split_kernel": bit-sliced; "decode_ms_pair_kernel" /
+ * `variant` ("decode_ms_bs_kernel" / "decode_ms_bs_refill_kernel" / "decode_ms_bs_split_kernel" / "decode_ms_bs_split_refill_kernel": bit-sliced; "decode_ms_pair_kernel" /
  * "decode_ms_kernel": the f32-pipe kernels) -- the default dispatch depends on the batch size; harnesses label their
  * measurements with it.  The launcher and this function share one predicate (csrc/decode_ms_i8.hip: pick_i8_kernel).
  * "" for a bad code and for a request this build has no kernel for (the batched call then returns LABRADOR_LDPC_HIP_EUNSUPPORTED);

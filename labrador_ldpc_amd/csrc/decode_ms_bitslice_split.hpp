@@ -237,6 +237,226 @@ struct SplitGroup {
     }
     // ordinal of block column c among the owned ones (the epilogue's hard-decision words alias the LLR planes)
     static constexpr int c_slot(int c) { int s = 0; for (int i = 0; i < c; ++i) s += GEO::owns_col(i) ? 1 : 0; return s; }
+
+    // ---- slot refill (round 6; decode_refill of decode_ms_bitslice.hpp for a group shared by two waves) --------------------------------
+    // A slot whose codeword is finished hands in its results and takes the workgroup's next frame while the other slots iterate.  Both
+    // waves run the SAME bookkeeping on the same verdicts (stage_finish: identical in both), so they agree on every slot and frame
+    // without talking; each emits the output dwords of ITS block columns and loads the LLRs of ITS transmitted columns, per slot and
+    // cooperatively (one (column, lane) unit per lane).  Sixteen slots (TM1280) would cost 32 scalar registers and a 16-way unrolled
+    // event as scalars: iteration counts and frames live in two vector registers (a lane holds its slot's value), verdicts are lane
+    // masks spread over a slot's lanes by scalar shifts, and an event walks the finished slots in a run-time loop (v_readlane for the
+    // slot's frame).  Frames come in CHUNKS [lo, hi) from `draw()`, which hands BOTH waves the same sequence (the kernel: wave 0 draws
+    // from the launch's queue word and passes the ticket on through LDS behind a barrier; both waves ask at the same points).
+    // Scratch in LDS: this wave's exchange buffer, idle between stage_fetch and the next stage_publish: [hard-decision words of the
+    // owned columns | staging slab].
+    static constexpr int NCOLS_OWN = GEO::NCOLS_OWN, NTX_OWN = GEO::NTX_OWN, N_OWN = NTX_OWN * M;
+    static constexpr int RF_HARD = XO, RF_STAGE = XO + NCOLS_OWN * 256;
+    static_assert(NCOLS_OWN <= 8 && NCOLS_OWN * 256 + N_OWN + 16 * (N_OWN / 256) <= LAY::XBYTES, "the refill's scratch fits the exchange buffer");
+    // the i-th owned block column / owned transmitted column, as packed 4-bit literals
+    static constexpr uint32_t own_cols_lit(bool tx_only)
+    {
+        uint32_t lit = 0;
+        int i = 0;
+        for (int c = 0; c < NCOLS; ++c)
+            if (GEO::owns_col(c) && (!tx_only || c < NTX)) lit |= (uint32_t)c << (4 * i++);
+        return lit;
+    }
+    static constexpr uint64_t all_lanes_of(int) { return W == 64 ? ~0ull : ((1ull << (W & 63)) - 1); }
+    V it_v, fr_v;                          // per lane: iterations done by / frame of the lane's slot
+    uint64_t rf_active = 0, rf_fin = ~0ull, rf_ok = 0;
+    uint32_t rf_next = 0, rf_end = 0;      // the current chunk's next frame without a slot, its end
+    bool rf_supply = true;                 // draw() has not said "no more" yet
+    static constexpr int RF_ROUNDS = (N_OWN + 1023) / 1024;
+    V rf_ahead[RF_ROUNDS][4];              // the LLR bytes (owned columns) of the next frame, requested one frame ahead of their use
+    uint32_t rf_ahead_frame = NO_FRAME;
+
+    // the next frame of the supply (a new chunk from draw() when the current one is used up), or NO_FRAME
+    template <class DRAW> BS_FN uint32_t rf_take(DRAW draw)
+    {
+        if (rf_next == rf_end) {
+            if (!rf_supply) return NO_FRAME;
+            const uint64_t chunk = draw();
+            if (chunk == 0) { rf_supply = false; return NO_FRAME; }
+            rf_next = (uint32_t)chunk;
+            rf_end = (uint32_t)(chunk >> 32);
+        }
+        return rf_next++;
+    }
+    template <class DRAW> BS_FN void rf_look_ahead(B &b, DRAW draw)
+    {
+        rf_ahead_frame = rf_take(draw);
+        if (rf_ahead_frame != NO_FRAME) fetch_owned(b, llrs + (size_t)rf_ahead_frame * GEO::N);
+    }
+
+    // a lane mask in which every slot with a set lane has ALL its lanes set
+    static BS_FN uint64_t spread_slots(uint64_t m)
+    {
+        if constexpr (W == 64) return m ? ~0ull : 0ull;
+        else {
+            constexpr uint64_t FIRST = []() constexpr { uint64_t f = 0; for (int g = 0; g < G; ++g) f |= 1ull << (g * W); return f; }();
+            uint64_t t = m;
+            for (int sh = 1; sh < W; sh <<= 1) t |= t >> sh;       // (the slot's first lane collects the OR of the slot's lanes ...)
+            t &= FIRST;
+            for (int sh = 1; sh < W; sh <<= 1) t |= t << sh;       // (... and hands it back to all of them)
+            return t;
+        }
+    }
+
+    template <class DRAW>
+    BS_FN void refill_begin(B &b, const int8_t *llrs_all, uint8_t *output_all, uint32_t *iters_all, uint8_t *success_all, DRAW draw)
+    {
+        d.init_lane(b);
+        lane = d.lane;
+        lw = B::and_(lane, B::c(W - 1));
+        llrs = llrs_all; output = output_all; iters = iters_all; success = success_all;
+        d.reset_state(b);
+        d.prime_perm(b);
+        it_v = B::c(0); fr_v = B::c(0);
+        rf_active = 0; rf_fin = ~0ull; rf_ok = 0;
+        rf_next = 0; rf_end = 0; rf_supply = true;
+        extra_fail = B::c(0);
+        rf_look_ahead(b, draw);
+    }
+
+    // the verdict of the iteration just run (the same in both waves): converged slots finish with (true, their iteration index), the
+    // others count on; slots at the iteration cap finish as they are (decoder.rs:453-474)
+    BS_FN void refill_verdict(B &b, uint32_t maxiters)
+    {
+        const V fail = B::or_(d.fail, extra_fail);
+        const uint64_t unsat = spread_slots(b.ballot(fail));
+        const uint64_t won = rf_active & ~unsat;
+        rf_fin |= won;
+        rf_ok |= won;
+        it_v = B::select_lanes(rf_active & unsat, B::add(it_v, B::c(1)), it_v);
+        refill_expire(b, maxiters);
+    }
+    BS_FN void refill_expire(B &b, uint32_t maxiters)
+    {
+        rf_fin |= rf_active & b.ballot(B::not_(B::less_u(it_v, B::c(maxiters))));          // it >= max_iters (max_iters = 0: at once)
+    }
+
+    // ---- an EVENT: the finished slots hand in their results, free slots take the next frames.  draw() -> (lo | (uint64_t)hi << 32) of
+    // the next chunk, or 0 when there is none left (it is then not asked again) ----
+    template <class DRAW>
+    BS_FN void refill_event(B &b, DRAW draw)
+    {
+        d.reinit_lane();
+        lane = d.lane;
+        lw = B::and_(lane, B::c(W - 1));
+        uint64_t done = rf_fin & rf_active;
+        if (done) {
+            sfor<0, NCOLS>([&](auto C_) {
+                constexpr int c = decltype(C_)::value;
+                if constexpr (GEO::owns_col(c)) b.lds_write32(B::add(B::shl(lane, 2), B::c(RF_HARD + c_slot(c) * 256)), d.hard[c]);
+            });
+            B::mem_fence();
+            while (done) {
+                const int first = __builtin_ctzll(done);                                  // the slot's first lane
+                const uint32_t f = b.readlane(fr_v, first), itv = b.readlane(it_v, first);
+                emit_owned(b, first, output + (size_t)f * GEO::OUT_LEN, iters + f, success + f, itv, (uint32_t)((rf_ok >> first) & 1));
+                done &= ~(all_lanes_of(0) << first);
+            }
+        }
+        rf_active &= ~rf_fin;
+        uint64_t vacant = rf_fin, fresh = 0;
+        while (vacant && rf_ahead_frame != NO_FRAME) {
+            const int first = __builtin_ctzll(vacant);
+            const uint64_t gmask = all_lanes_of(0) << first;
+            const uint32_t f = rf_ahead_frame;
+            place_owned(b, first);
+            rf_look_ahead(b, draw);
+            fr_v = B::select_lanes(gmask, B::c(f), fr_v);
+            it_v = B::select_lanes(gmask, B::c(0), it_v);
+            fresh |= gmask;
+            vacant &= ~gmask;
+        }
+        rf_active |= fresh;
+        if (fresh) d.reset_state(b, fresh);
+        rf_fin = 0; rf_ok = 0;
+    }
+
+    // the finished codeword of the slot whose first lane is `first`: the hard-decision words of the OWNED block columns -> their output
+    // dwords, one (column, lane) unit per lane; wave 0 also stores the iteration count and the flag
+    BS_FN void emit_owned(B &b, int first, uint8_t *out, uint32_t *iters_p, uint8_t *ok_p, uint32_t iters_v, uint32_t ok_v)
+    {
+        constexpr int UNITS = NCOLS_OWN * W;
+        sfor<0, (UNITS + 63) / 64>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            const V u = B::add(lane, B::c(64 * r));
+            const V valid = B::less_u(u, B::c(UNITS));
+            const V i = B::and_(B::shr(u, ilog2c(W)), valid);                         // ordinal of the owned column
+            const V c = B::bfe(B::c(own_cols_lit(false)), B::shl(i, 2), 4);            // the column itself
+            const V ulw = B::and_(u, B::c(W - 1));
+            const V b0 = B::shl(B::and_(ulw, B::c(L - 1)), 5 - ilog2c(L));
+            const V qbase = B::add(B::shl(i, 8), B::shl(B::add(B::c(first), B::and_(ulw, B::c(~(L - 1) & (W - 1)))), 2));
+            V o = B::c(0);
+            sfor<0, L>([&](auto LL_) {
+                constexpr int l2 = decltype(LL_)::value;
+                const V w = B::shr_v(b.lds_read32(B::add(qbase, B::c(RF_HARD + 4 * l2))), b0);
+                sfor<0, 32 / L>([&](auto K_) {
+                    constexpr int k = decltype(K_)::value;
+                    constexpr int t = l2 + L * k;
+                    constexpr int pos = 8 * (t / 8) + 7 - (t % 8);
+                    o = B::or_(o, B::shl(B::and_(B::shr(w, k), B::c(1)), pos));
+                });
+            });
+            b.gstore32(out, B::add(B::mul_u(c, (uint32_t)(M / 8)), B::shl(ulw, 2)), o, valid);
+        });
+        if constexpr (HALF == 0) {
+            const V first_lane = B::eq(lane, B::c(0));
+            b.gstore32(iters_p, B::c(0), B::c(iters_v), first_lane);
+            b.gstore8(ok_p, B::c(0), B::c(ok_v), first_lane);
+        }
+    }
+
+    // position among the owned columns' bytes of the lane's 16 bytes of round R (the last round's idle lanes repeat the last 16)
+    template <int R> BS_FN V rf_pos() const
+    {
+        V p = B::add(B::shl(lane, 4), B::c(1024 * R));
+        if constexpr (1024 * (R + 1) > N_OWN) {
+            const V over = B::less_u(B::c(N_OWN - 16), p);
+            p = B::template bitop3<TT_MUX>(over, B::c(N_OWN - 16), p);
+        }
+        return p;
+    }
+    // the LLR bytes of the OWNED transmitted columns of a frame into rf_ahead (16 bytes per lane and round)
+    BS_FN void fetch_owned(B &b, const int8_t *src)
+    {
+        sfor<0, RF_ROUNDS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            const V p = rf_pos<r>();
+            const V c = B::bfe(B::c(own_cols_lit(true)), B::shl(B::shr(p, ilog2c(M)), 2), 4);
+            b.gload128(src, B::add(B::shl(c, ilog2c(M)), B::and_(p, B::c(M - 1))), rf_ahead[r]);
+        });
+    }
+    // a fresh codeword for the slot whose first lane is `first`: rf_ahead -> staging slab -> one (column, lane) unit of 32 LLRs per
+    // lane -> its 8 bit planes
+    BS_FN void place_owned(B &b, int first)
+    {
+        constexpr int UNITS = NTX_OWN * W;
+        sfor<0, RF_ROUNDS>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            const V p = rf_pos<r>();
+            b.lds_write128(B::add(B::add(p, B::shl(B::shr(p, 8), 4)), B::c(RF_STAGE)), rf_ahead[r]);
+        });
+        B::mem_fence();
+        sfor<0, (UNITS + 63) / 64>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            const V u = B::add(lane, B::c(64 * r));
+            const V valid = B::less_u(u, B::c(UNITS));
+            const V i = B::and_(B::shr(u, ilog2c(W)), valid);
+            const V ulw = B::and_(u, B::c(W - 1));
+            const V p0 = B::add(B::add(B::shl(i, ilog2c(M)), B::shl(B::shr(ulw, ilog2c(L)), ilog2c(Q))), B::and_(ulw, B::c(L - 1)));
+            V X[8];
+            gather_planes<CODE>(b, p0, RF_STAGE, X);
+            const V at = B::add(B::mul_u(i, (uint32_t)(LLRP * 256)), B::shl(B::add(B::c(first), ulw), 2));
+            sfor<0, 8>([&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                b.lds_write32_if(B::add(at, B::c(GEO::LDS_LLR + k * 256)), X[k], valid);
+            });
+        });
+        B::mem_fence();
+    }
 };
 
 // One wave's program for a group: the HIP kernel calls it with a workgroup barrier for SYNC, every wave of the pair with its HALF.
@@ -256,6 +476,30 @@ BS_FN void decode_group_split(B &b, SplitGroup<CODE, B, HALF> &g, const int8_t *
     }
     sync();                                    // (the epilogue's hard-decision words alias nothing the other wave reads, but the next
     g.epilogue(b);                             //  group's staging slab is this buffer)
+}
+
+// One wave's program with slot refill: events between the iterations, the iteration itself is decode_group_split's (two barriers).
+// Both waves take the same branches: every condition is a function of the shared verdicts and of draw()'s shared sequence.
+template <int CODE, class B, int HALF, class SYNC, class DRAW>
+BS_FN void decode_refill_split(B &b, SplitGroup<CODE, B, HALF> &g, const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, uint32_t maxiters,
+                               SYNC sync, DRAW draw)
+{
+    g.refill_begin(b, llrs, out, iters, ok, draw);
+    for (;;) {
+        g.refill_event(b, draw);
+        g.refill_expire(b, maxiters);                 // (max_iters = 0: the fresh slots are at the cap already)
+        if (g.rf_fin) continue;
+        if (!g.rf_active) break;
+        do {
+            g.d.columns(b, ~g.rf_active);
+            g.stage_publish(b);
+            sync();
+            g.stage_merge(b);
+            sync();
+            g.stage_fetch(b);
+            g.refill_verdict(b, maxiters);
+        } while (!g.rf_fin);
+    }
 }
 
 }  // namespace bs

@@ -99,6 +99,75 @@ decode_ms_bs_split_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__
     else split_wave<CODE, 1>(lds, llrs, output, iters, success, batch, maxiters, ngroups);
 }
 
+// ---- slot refill on the two-wave kernel (decode_refill_split): persistent workgroups; wave 0 draws chunks of frames from the launch's
+// queue word and hands the ticket to wave 1 through an LDS word behind a barrier (both waves ask at the same points of their identical
+// bookkeeping); the word is self-resetting like decode_ms_bs_refill_kernel's: every workgroup draws until its first ticket beyond the last chunk.
+template <int CODE, int HALF>
+__device__ __forceinline__ void split_wave_refill(char *lds, uint32_t *ticket_word, const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success,
+                                                  uint32_t batch, uint32_t maxiters, uint32_t *queue, uint32_t chunk)
+{
+    HipBackend b{lds + SplitLayout<CODE>::template priv<HALF>()};
+    SplitGroup<CODE, HipBackend, HALF> g;
+    g.init(b);
+    const uint32_t nchunks = (batch + chunk - 1) / chunk;
+    uint32_t draws = 0;
+    auto draw = [&]() -> uint64_t {
+        // two ticket words, used alternately: wave 0 may write draw k + 1's ticket before wave 1 has read draw k's (only the barrier of
+        // draw k + 1 lies between them), never draw k + 2's
+        uint32_t *word = ticket_word + (draws++ & 1u);
+        if (HALF == 0 && threadIdx.x == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == nchunks + gridDim.x - 1) __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the launch's last draw
+            *word = t;
+        }
+        __syncthreads();
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)*word);
+        if (t >= nchunks) return 0;
+        const uint32_t lo = t * chunk, hi = batch - lo < chunk ? batch : lo + chunk;
+        return (uint64_t)lo | (uint64_t)hi << 32;
+    };
+    decode_refill_split<CODE, HipBackend, HALF>(b, g, llrs, output, iters, success, maxiters, [] { __syncthreads(); }, draw);
+}
+
+template <int CODE>
+__global__ void __launch_bounds__(128, 2)
+decode_ms_bs_split_refill_kernel(const int8_t *__restrict__ llrs, uint8_t *__restrict__ output, uint32_t *__restrict__ iters, uint8_t *__restrict__ success,
+                                 uint32_t batch, uint32_t maxiters, uint32_t *queue, uint32_t chunk)
+{
+    __shared__ __attribute__((aligned(16))) char lds[SplitLayout<CODE>::BYTES];
+    __shared__ uint32_t ticket_word[2];
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) split_wave_refill<CODE, 0>(lds, ticket_word, llrs, output, iters, success, batch, maxiters, queue, chunk);
+    else split_wave_refill<CODE, 1>(lds, ticket_word, llrs, output, iters, success, batch, maxiters, queue, chunk);
+}
+
+template <int CODE>
+hipError_t launch_split_refill(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream,
+                               uint32_t *queue)
+{
+    constexpr int G = Geo<CODE>::G;
+    if (batch == 0) return hipSuccess;
+    if (batch > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    static std::atomic<int> cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int resident = cached[dev].load(std::memory_order_relaxed);
+    if (resident == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_ms_bs_split_refill_kernel<CODE>, 128, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = per_cu * cus;
+        cached[dev].store(resident, std::memory_order_relaxed);
+    }
+    // frames per draw: four rounds of slots, fewer for short launches (at least ~4 draws per resident workgroup)
+    size_t chunk = 4 * (size_t)G;
+    while (chunk > (size_t)G && batch / chunk < 4 * (size_t)resident) chunk /= 2;
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    const size_t grid = nchunks < (size_t)resident ? nchunks : (size_t)resident;
+    hipLaunchKernelGGL((decode_ms_bs_split_refill_kernel<CODE>), dim3((unsigned)grid), dim3(128), 0, stream, llrs, output, iters, success, (uint32_t)batch, maxiters,
+                       queue, (uint32_t)chunk);
+    return hipGetLastError();
+}
+
 template <int CODE>
 hipError_t launch_split(const int8_t *llrs, uint8_t *output, uint32_t *iters, uint8_t *success, size_t batch, uint32_t maxiters, hipStream_t stream)
 {
@@ -168,11 +237,20 @@ hipError_t launch_decode_ms_bitsliced_unit2(int code, const int8_t *llrs, uint8_
 {
     uint32_t *queue = refill ? bs::bs_queue_word(stream) : nullptr;
     switch (code) {
-        case TM1280: return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM1280:
+            if (queue) return bs::launch_split_refill<TM1280>(llrs, output, iters, success, batch, maxiters, stream, queue);
+            return bs::launch_split<TM1280>(llrs, output, iters, success, batch, maxiters, stream);
         case TM1536:
             if (queue) return bs::launch_refill<TM1536>(llrs, output, iters, success, batch, maxiters, stream, queue);
             return bs::launch<TM1536>(llrs, output, iters, success, batch, maxiters, stream);
-        case TM5120: return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
+        case TM5120:
+#ifndef BS_REFILL_TM5120
+#define BS_REFILL_TM5120 0
+#endif
+#if BS_REFILL_TM5120
+            if (queue) return bs::launch_split_refill<TM5120>(llrs, output, iters, success, batch, maxiters, stream, queue);
+#endif
+            return bs::launch_split<TM5120>(llrs, output, iters, success, batch, maxiters, stream);
         case TM6144: return bs::launch<TM6144>(llrs, output, iters, success, batch, maxiters, stream);
         default: return hipErrorInvalidConfiguration;
     }

@@ -66,9 +66,9 @@ const char *decode_ms_i8_kernel_name(int code, int variant, size_t batch)
     if (!valid_code(code) || variant < 0) return "";
     LDPC_SPLIT_VARIANT();
     switch (pick_i8_kernel(code, variant, lflags, batch, true)) {
-        // (TM1536: the slot-refill kernel unless the fixed distribution is asked for -- and on streams without a queue word)
+        // (TM1536, TM1280: the slot-refill kernels unless the fixed distribution is asked for -- and on streams without a queue word)
         case I8Kernel::BITSLICED:       return (code == TM1536 && !(lflags & LF_STATIC)) ? "decode_ms_bs_refill_kernel" : "decode_ms_bs_kernel";
-        case I8Kernel::BITSLICED_SPLIT: return "decode_ms_bs_split_kernel";
+        case I8Kernel::BITSLICED_SPLIT: return (code == TM1280 && !(lflags & LF_STATIC)) ? "decode_ms_bs_split_refill_kernel" : "decode_ms_bs_split_kernel";
         case I8Kernel::PAIR:            return "decode_ms_pair_kernel";
         case I8Kernel::PIPE:            return "decode_ms_kernel";
         default:                        return "";

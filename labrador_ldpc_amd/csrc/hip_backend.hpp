@@ -86,6 +86,7 @@ struct HipBackend {
         return r;
     }
     static BS_FN uint64_t ballot(V x) { return __ballot(x != 0u); }
+    static BS_FN uint32_t readlane(V x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }      // (l wave-uniform)
     BS_FN V plane_of(uint64_t m) const { return ((m >> (threadIdx.x & 63u)) & 1ull) ? 0xFFFFFFFFu : 0u; }
 };
 

@@ -98,6 +98,7 @@ struct EmuBackend {
     static void gstore32_stream(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) std::memcpy((char *)p + off.l[i], &v.l[i], 4); }
     static void gstore8(void *p, const V &off, const V &v, const V &pred) { for (int i = 0; i < 64; ++i) if (pred.l[i]) ((uint8_t *)p)[off.l[i]] = (uint8_t)v.l[i]; }
     static V select_lanes(uint64_t m, const V &a, const V &b) { V r; for (int i = 0; i < 64; ++i) r.l[i] = ((m >> i) & 1) ? a.l[i] : b.l[i]; return r; }
+    static uint32_t readlane(const V &x, int l) { return x.l[l & 63]; }
     static uint64_t ballot(const V &x) { uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(x.l[i] != 0) << i; return m; }
     static V plane_of(uint64_t m) { V r; for (int i = 0; i < 64; ++i) r.l[i] = ((m >> i) & 1) ? 0xFFFFFFFFu : 0u; return r; }
 };
@@ -162,6 +163,45 @@ int run_split(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, si
     return 0;
 }
 
+// slot refill on the two-wave kernel (decode_range_split): ONE emulated workgroup takes the whole batch as its range; the two halves
+// run stage by stage on one LDS store, as run_split does
+template <int CODE>
+int run_split_refill(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    using namespace ldpc::bs;
+    using LAY = SplitLayout<CODE>;
+    auto store = std::make_shared<std::vector<uint8_t>>(LAY::BYTES, 0xA5);
+    EmuBackend b0(store, LAY::PRIV0), b1(store, LAY::PRIV1);
+    SplitGroup<CODE, EmuBackend, 0> w0;
+    SplitGroup<CODE, EmuBackend, 1> w1;
+    w0.init(b0); w1.init(b1);
+    // chunks of 5 frames (not a multiple of any G): each wave walks the same sequence with a cursor of its own
+    uint32_t cur0 = 0, cur1 = 0;
+    auto draw_from = [&](uint32_t &cur) { return [&cur, batch]() -> uint64_t {
+        if (cur >= batch) return 0;
+        const uint32_t lo = cur, hi = (uint32_t)(lo + 5 < batch ? lo + 5 : batch);
+        cur = hi;
+        return (uint64_t)lo | (uint64_t)hi << 32; }; };
+    w0.refill_begin(b0, llrs, out, iters, ok, draw_from(cur0));
+    w1.refill_begin(b1, llrs, out, iters, ok, draw_from(cur1));
+    for (;;) {
+        w0.refill_event(b0, draw_from(cur0)); w1.refill_event(b1, draw_from(cur1));
+        w0.refill_expire(b0, maxiters); w1.refill_expire(b1, maxiters);
+        if (w0.rf_fin != w1.rf_fin || w0.rf_active != w1.rf_active) return 2;        // the two waves must agree on every slot
+        if (w0.rf_fin) continue;
+        if (!w0.rf_active) break;
+        do {
+            w0.d.columns(b0, ~w0.rf_active); w1.d.columns(b1, ~w1.rf_active);
+            w0.stage_publish(b0); w1.stage_publish(b1);
+            w0.stage_merge(b0); w1.stage_merge(b1);
+            w0.stage_fetch(b0); w1.stage_fetch(b1);
+            w0.refill_verdict(b0, maxiters); w1.refill_verdict(b1, maxiters);
+            if (w0.rf_fin != w1.rf_fin || w0.rf_ok != w1.rf_ok) return 3;
+        } while (!w0.rf_fin);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // One code per shared object (-DEMU_CODE=TM8192 ...): the six instantiations compile in parallel (tests/test_bitslice_emu.py).
@@ -193,6 +233,11 @@ extern "C" int bs_emu_decode_split(const int8_t *llrs, uint8_t *out, uint32_t *i
 extern "C" int bs_emu_decode_refill(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
 {
     return run_refill<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+}
+extern "C" int bs_emu_decode_split_refill(const int8_t *llrs, uint8_t *out, uint32_t *iters, uint8_t *ok, size_t batch, uint32_t maxiters)
+{
+    if constexpr (ldpc::bs::Geo<ldpc::EMU_CODE>::TWO_WAVES) return run_split_refill<ldpc::EMU_CODE>(llrs, out, iters, ok, batch, maxiters);
+    else return -1;
 }
 extern "C" int bs_emu_group(void) { return ldpc::bs::Geo<ldpc::EMU_CODE>::G; }
 extern "C" int bs_emu_code(void) { return ldpc::EMU_CODE; }

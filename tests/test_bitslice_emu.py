@@ -43,17 +43,20 @@ def emu():
         L.bs_emu_decode_bf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         L.bs_emu_decode_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         L.bs_emu_decode_refill.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        L.bs_emu_decode_split_refill.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         assert L.bs_emu_code() == oracle.CODES.index(name)
         loaded[oracle.CODES.index(name)] = L
 
     def decode(code, llrs, maxiters, split=False, refill=False):
         """split: the two-waves-per-group kernel of the rate-4/5 codes (decode_ms_bitslice_split.hpp), its two halves run alternately;
-        refill: the slot-refill driver (decode_refill): ONE emulated wave takes the whole batch, a finished slot the next frame"""
+        refill: the slot-refill driver (decode_refill; with split: decode_refill_split, the two halves drawing the same chunks of 5
+        frames each with a cursor of its own): ONE emulated wave (pair) takes the whole batch, a finished slot the next frame"""
         llrs = np.ascontiguousarray(llrs, dtype=np.int8)
         B = llrs.shape[0]
         out = np.full((B, oracle.output_len(code)), 0xEE, np.uint8)
         it, ok = np.full(B, 0xEEEEEEEE, np.uint32), np.full(B, 0xEE, np.uint8)
-        fn = loaded[code].bs_emu_decode_refill if refill else loaded[code].bs_emu_decode_split if split else loaded[code].bs_emu_decode
+        L = loaded[code]
+        fn = (L.bs_emu_decode_split_refill if split else L.bs_emu_decode_refill) if refill else L.bs_emu_decode_split if split else L.bs_emu_decode
         assert fn(llrs.ctypes.data, out.ctypes.data, it.ctypes.data, ok.ctypes.data, B, maxiters) == 0
         return out, it, ok
     def decode_bf(code, hard, maxiters):
@@ -131,6 +134,29 @@ def test_emulated_slot_refill_equals_the_oracle(emu, name):
                        rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)])
     for maxiters in (25, 1):
         _same(emu, code, corner, maxiters, refill=True)
+
+
+@pytest.mark.parametrize("name", ["TM1280", "TM5120"])
+def test_emulated_two_wave_slot_refill_equals_the_oracle(emu, name):
+    """Slot refill on the two-wave kernel (decode_refill_split): both waves of a group keep the slots' iteration counts and frame
+    numbers in a register each (lane = slot's lane), reach the same verdicts from the exchanged row states, and draw the same chunks
+    of the frame supply; each places only the block columns it owns.  Pins: the vector bookkeeping, the owned-column literals of the
+    prologue and epilogue, the chunked supply running dry in the middle of an event, the look-ahead frame across a chunk border."""
+    code = oracle.CODES.index(name)
+    rng = np.random.default_rng(950 + code)
+    G = emu.group(code)
+    parts = [oracle.awgn_llrs(code, rng, f, e, np.int8, scale=s, lim=l)[0] for e, s, l, f in
+             ((3.5, 8.0, 31, 3 * G + 1), (1.0, 30.0, 127, 3), (5.5, 16.0, 127, G + 2), (3.0, 8.0, 31, G))]
+    llrs = np.concatenate(parts)
+    rng.shuffle(llrs)
+    for frames in (llrs.shape[0], 1, max(1, G - 1), 5, 6):
+        for maxiters in (0, 1, 2, 7, 25):
+            it, ok = _same(emu, code, llrs[:frames], maxiters, split=True, refill=True)
+    N = llrs.shape[1]
+    corner = np.stack([np.zeros(N, np.int8), np.full(N, -128, np.int8), np.full(N, 127, np.int8), rng.integers(-128, 128, N).astype(np.int8),
+                       rng.choice(np.array([-128, 127, 0, 1, -1], np.int8), N)])
+    for maxiters in (25, 1):
+        _same(emu, code, corner, maxiters, split=True, refill=True)
 
 
 @pytest.mark.parametrize("name", ["TM2048", "TM8192"])

@@ -19,7 +19,7 @@ CODES = [LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048, LDPCCode.TM5120, LDP
 # (the rate-4/5 codes' bit-sliced kernel shares a codeword group between two waves: csrc/decode_ms_bitslice_split.hpp)
 # TM1536's default is the SLOT-REFILL kernel (decode_refill: a finished slot takes the wave's next frame at once); 64 | 256 names its
 # lockstep kernel (decode_group), which streams without a queue word still run: both must return the oracle's bytes
-KERNELS = [(c, BS) for c in CODES] + [(LDPCCode.TM1536, BS | 256)]
+KERNELS = [(c, BS) for c in CODES] + [(LDPCCode.TM1536, BS | 256), (LDPCCode.TM1280, BS | 256)]
 KERNEL_IDS = [f"{c.name}-{v}" for c, v in KERNELS]
 
 
@@ -138,17 +138,19 @@ def test_variant_64_is_refused_where_it_does_not_exist():
         code.decode_ms_batch(even, 5, output=out_odd, variant=BS)
 
 
-def test_slot_refill_hands_out_every_frame_exactly_once():
-    """TM1536 through the slot-refill kernel on batches around its chunk and grid sizes -- 1 frame, fewer frames than a wave has slots,
-    one frame more than the resident waves hold, a batch that ends inside a chunk -- with frames that finish after 3 ... 25 iterations
-    and frames that never do: every frame's results equal the lockstep kernel's (whose equality with the oracle the tests above pin),
-    twice in a row on one stream (the queue word must be back at zero) and on a second stream."""
-    code = LDPCCode.TM1536
+@pytest.mark.parametrize("code", [LDPCCode.TM1536, LDPCCode.TM1280], ids=lambda c: c.name)
+def test_slot_refill_hands_out_every_frame_exactly_once(code):
+    """TM1536 (one wave per group) and TM1280 (two waves per group, both drawing the same chunks) through their slot-refill kernels on
+    batches around their chunk and grid sizes -- 1 frame, fewer frames than a wave has slots, one frame more than a chunk, a batch that
+    ends inside a chunk -- with frames that finish after 3 ... 25 iterations and frames that never do: every frame's results equal the
+    lockstep kernel's (whose equality with the oracle the tests above pin), twice in a row on one stream (the queue word must be back
+    at zero) and on a second stream."""
     rng = np.random.default_rng(77)
-    pool = [oracle.awgn_llrs(code, rng, 512, e, np.int8, scale=s, lim=l)[0] for e, s, l in ((3.0, 8.0, 31), (1.0, 30.0, 127), (5.0, 8.0, 31))]
+    hi = 1.5 if code is LDPCCode.TM1280 else 0.0
+    pool = [oracle.awgn_llrs(code, rng, 512, e, np.int8, scale=s, lim=l)[0] for e, s, l in ((3.0 + hi, 8.0, 31), (1.0, 30.0, 127), (5.0 + hi, 8.0, 31))]
     llrs = np.concatenate(pool)
     rng.shuffle(llrs)
-    for frames in (1, 7, 8, 9, 63, 1025, 1536):
+    for frames in (1, 7, 8, 9, 15, 16, 17, 63, 65, 1025, 1536):
         d = torch.from_numpy(llrs[:frames]).cuda()
         ref = [t.cpu().numpy() for t in code.decode_ms_batch(d, 25, variant=BS | 256)]
         for rep in range(2):
@@ -159,7 +161,7 @@ def test_slot_refill_hands_out_every_frame_exactly_once():
             got = code.decode_ms_batch(d, 25, variant=BS)
         st.synchronize()
         assert all((a == b.cpu().numpy()).all() for a, b in zip(ref, got)), frames
-    # a large batch against the default dispatch (which IS the refill kernel from 16 384 frames up) and the oracle on a sample
+    # a large batch against the default dispatch (which IS the refill kernel at this size) and the oracle on a sample
     big = torch.from_numpy(np.tile(llrs, (40, 1))).cuda()
     a = code.decode_ms_batch(big, 25)
     b_ = code.decode_ms_batch(big, 25, variant=BS | 256)

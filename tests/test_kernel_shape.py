@@ -170,6 +170,20 @@ def test_bit_sliced_iteration_loops_carry_at_most_a_few_scratch_reloads(built_ob
             assert waits < perm, f"{name}: {waits} s_waitcnt for {perm} ds_bpermute_b32 (whole kernel): the per-job wait is gone"
         seen += 1
     assert seen == 2
+    # slot refill on the two-wave kernel (TM1280's default, round 6): no scratch anywhere, the lane permutations still DPP quad moves,
+    # and the refill's global accesses (LLR look-ahead, results) all outside the iteration -- which here lies between the first and the
+    # last DPP move
+    seen = 0
+    for name, body in kernels.items():
+        if "decode_ms_bs_split_refill_kernel" not in name:
+            continue
+        assert "ILi3E" in name, name
+        assert not any(t.startswith("scratch_") for t in body), name
+        assert sum(1 for t in body if t.startswith("ds_bpermute_b32")) == 0, name
+        dpp = [i for i, t in enumerate(body) if t.startswith("v_mov_b32_dpp")]
+        assert len(dpp) >= 200, name
+        seen += 1
+    assert seen == 1
     # the rate-2/3 kernels run the same one-wait-per-job schedule; the rate-1/2 kernels cannot (no registers) but keep four edges'
     # "v != 0" planes in LDS instead of scratch
     for name, body in kernels.items():
