@@ -270,7 +270,8 @@ enum labrador_ldpc_hip_variant {
     LABRADOR_LDPC_HIP_VARIANT_F64_WORKSPACE = 100,  /* f64: the general kernel with its messages in a device workspace */
     /* flags */
     LABRADOR_LDPC_HIP_VARIANT_STATIC        = 256,  /* fixed-stride distribution of the codewords instead of the launch's queue; with
-                                                       BITSLICE: the lockstep kernel instead of the slot-refill one (TM1536, TM1280) */
+                                                       BITSLICE: the lockstep kernel instead of the slot-refill one (TM1536, TM1280: by
+                                                       name at any batch size, in the default dispatch from 65 536 frames up) */
     LABRADOR_LDPC_HIP_VARIANT_NAN_ONE_PASS  = 512,  /* TM5120 / TM1280 f32: NaN LLRs handled inside the one kernel ... */
     LABRADOR_LDPC_HIP_VARIANT_NAN_TWO_PASS  = 1024  /* ... or by a second launch over marked codewords (the default from ~1000 frames) */
 };

@@ -59,6 +59,17 @@ static I8Kernel pick_i8_kernel(int code, int variant, unsigned lflags, size_t ba
     return pipe_variant_built(code, variant) ? I8Kernel::PIPE : I8Kernel::NONE;
 }
 
+// Slot refill (TM1536, TM1280: a finished codeword's lanes take the next frame at once): by name -- `variant` 64 without STATIC -- at
+// any batch size; in the default dispatch from 4 frames per resident slot up (2 048 waves x 8, 1 024 wave pairs x 16 = 16 384 slots on
+// 256 CUs): with fewer frames per slot there is little to refill with and the per-slot events cost more than the lockstep loses
+// (tools/bs_crossover.py, profiles/r06_kbench/bs_crossover_refill.txt: TM1536 break-even at 65 536 frames, TM1280 between 32 768 and 65 536).
+constexpr size_t REFILL_MIN_BATCH = 65536;
+static bool i8_refills(int code, int variant, unsigned lflags, size_t batch)
+{
+    if ((code != TM1536 && code != TM1280) || (lflags & LF_STATIC)) return false;
+    return variant == VARIANT_BITSLICE || batch >= REFILL_MIN_BATCH;
+}
+
 // the kernel labrador_ldpc_decode_ms_batch_i8 launches for a 4-byte-aligned batch of this size ("" = this build has none for the
 // request: the call returns LABRADOR_LDPC_HIP_EUNSUPPORTED).  Buffers that are not 4-byte aligned never take the bit-sliced kernels.
 const char *decode_ms_i8_kernel_name(int code, int variant, size_t batch)
@@ -66,9 +77,9 @@ const char *decode_ms_i8_kernel_name(int code, int variant, size_t batch)
     if (!valid_code(code) || variant < 0) return "";
     LDPC_SPLIT_VARIANT();
     switch (pick_i8_kernel(code, variant, lflags, batch, true)) {
-        // (TM1536, TM1280: the slot-refill kernels unless the fixed distribution is asked for -- and on streams without a queue word)
-        case I8Kernel::BITSLICED:       return (code == TM1536 && !(lflags & LF_STATIC)) ? "decode_ms_bs_refill_kernel" : "decode_ms_bs_kernel";
-        case I8Kernel::BITSLICED_SPLIT: return (code == TM1280 && !(lflags & LF_STATIC)) ? "decode_ms_bs_split_refill_kernel" : "decode_ms_bs_split_kernel";
+        // (the slot-refill kernels: i8_refills -- and on streams that have a queue word: all but a stream under capture)
+        case I8Kernel::BITSLICED:       return i8_refills(code, variant, lflags, batch) ? "decode_ms_bs_refill_kernel" : "decode_ms_bs_kernel";
+        case I8Kernel::BITSLICED_SPLIT: return i8_refills(code, variant, lflags, batch) ? "decode_ms_bs_split_refill_kernel" : "decode_ms_bs_split_kernel";
         case I8Kernel::PAIR:            return "decode_ms_pair_kernel";
         case I8Kernel::PIPE:            return "decode_ms_kernel";
         default:                        return "";
@@ -84,7 +95,7 @@ hipError_t launch_decode_ms<int8_t>(int code, int variant, const int8_t *llrs, u
     switch (pick_i8_kernel(code, variant, lflags, batch, bitslice_aligned(llrs, output))) {
         case I8Kernel::BITSLICED:
         case I8Kernel::BITSLICED_SPLIT:
-            return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream, (lflags & LF_STATIC) ? 0 : 1);
+            return launch_decode_ms_bitsliced(code, llrs, output, iters, success, batch, maxiters, stream, i8_refills(code, variant, lflags, batch) ? 1 : 0);
         case I8Kernel::PAIR:           // TM8192: pair-ownership kernel by default (decode_ms_pair.hpp), `variant` 2 / 4 = the (t, t + M/2) kernel
             return launch_pair<TM8192, int8_t>(llrs, output, iters, success, batch, maxiters, stream, lflags);
         case I8Kernel::PIPE:

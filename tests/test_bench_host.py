@@ -94,6 +94,11 @@ def test_roofline_of_prints_null_valu_issue_for_an_unprofiled_operating_point(tm
     assert b.kernel_name("TM8192", "i8", 0, 4096) == "decode_ms_bs_kernel" and b.kernel_name("TM8192", "i8", 0, 512) == "decode_ms_pair_kernel"
     assert b.kernel_name("TM8192", "i8", 256, 4096) == "decode_ms_pair_kernel"          # a launch flag keeps the f32-pipe kernel
     assert b.kernel_name("TC512", "i8", 0, 1 << 20) == "decode_ms_kernel"
+    # slot refill (TM1536, TM1280): by name at any size, by default from 65 536 frames up, never with the STATIC flag
+    for code, lock, refill in (("TM1536", "decode_ms_bs_kernel", "decode_ms_bs_refill_kernel"), ("TM1280", "decode_ms_bs_split_kernel", "decode_ms_bs_split_refill_kernel")):
+        assert b.kernel_name(code, "i8", 0, 65536) == refill and b.kernel_name(code, "i8", 0, 65535) == lock and b.kernel_name(code, "i8", 0, 1024) == "decode_ms_kernel"
+        assert b.kernel_name(code, "i8", 64, 8) == refill and b.kernel_name(code, "i8", 64 | 256, 1 << 20) == lock
+    assert b.kernel_name("TM5120", "i8", 0, 1 << 20) == "decode_ms_bs_split_kernel" and b.kernel_name("TM2048", "i8", 64, 1 << 20) == "decode_ms_bs_kernel"
 
 
 def test_an_alternative_library_build_never_gets_profile_figures(tmp_path, monkeypatch):

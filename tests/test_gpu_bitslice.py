@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BS = 64                                                       # `variant` of the bit-sliced kernel
 CODES = [LDPCCode.TM1280, LDPCCode.TM1536, LDPCCode.TM2048, LDPCCode.TM5120, LDPCCode.TM6144, LDPCCode.TM8192]
 # (the rate-4/5 codes' bit-sliced kernel shares a codeword group between two waves: csrc/decode_ms_bitslice_split.hpp)
-# TM1536's default is the SLOT-REFILL kernel (decode_refill: a finished slot takes the wave's next frame at once); 64 | 256 names its
-# lockstep kernel (decode_group), which streams without a queue word still run: both must return the oracle's bytes
+# `variant` 64 on TM1536 and TM1280 is the SLOT-REFILL kernel (decode_refill / decode_refill_split: a finished slot takes the wave's next
+# frame at once; the default dispatch picks it from 65 536 frames up); 64 | 256 names their lockstep kernels, which smaller default
+# batches and streams without a queue word run: both must return the oracle's bytes
 KERNELS = [(c, BS) for c in CODES] + [(LDPCCode.TM1536, BS | 256), (LDPCCode.TM1280, BS | 256)]
 KERNEL_IDS = [f"{c.name}-{v}" for c, v in KERNELS]
 
@@ -162,7 +163,9 @@ def test_slot_refill_hands_out_every_frame_exactly_once(code):
         st.synchronize()
         assert all((a == b.cpu().numpy()).all() for a, b in zip(ref, got)), frames
     # a large batch against the default dispatch (which IS the refill kernel at this size) and the oracle on a sample
-    big = torch.from_numpy(np.tile(llrs, (40, 1))).cuda()
+    big = torch.from_numpy(np.tile(llrs, (44, 1))).cuda()                 # 67 584 frames (the default dispatch refills from 65 536)
+    import labrador_ldpc_amd as la
+    assert la.lib.labrador_ldpc_hip_decode_ms_i8_kernel(int(code), 0, big.shape[0]).decode().endswith("refill_kernel")
     a = code.decode_ms_batch(big, 25)
     b_ = code.decode_ms_batch(big, 25, variant=BS | 256)
     assert all(bool((x == y).all()) for x, y in zip(a, b_))

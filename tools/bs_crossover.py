@@ -16,15 +16,15 @@ for code, ebn0 in CASES:
     for i in range(16):
         code.copy_encode(rng.integers(0, 256, code.k() // 8, dtype=np.uint8), pool[i])
     sigma = float(np.sqrt(1.0 / (2.0 * (code.k() / code.n()) * 10.0 ** (ebn0 / 10.0))))
-    top = 65536 if code == LDPCCode.TM1280 else 8192
+    top = 65536 if code in (LDPCCode.TM1280, LDPCCode.TM1536) else 8192
     llrs = code.awgn_frames(torch.from_numpy(pool).to(dev), top * G, sigma, seed=5, dtype="i8")
     old = 32 if code == LDPCCode.TM8192 else 1
-    print(f"{code.name} (G = {G} codewords per wave), us per call: groups  f32-pipe  bit-sliced", flush=True)
+    print(f"{code.name} (G = {G} codewords per wave), us per call: groups  f32-pipe  bit-sliced  (bit-sliced lockstep, 64 | 256)", flush=True)
     for groups in (1, 16, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 8192, 16384, 32768, 65536):
         if groups > top: break
         l = llrs[: groups * G]
         t = {}
-        for name, variant in (("old", old), ("bs", 64)):
+        for name, variant in (("old", old), ("bs", 64), ("ls", 64 | 256)):
             for _ in range(3):
                 code.decode_ms_batch(l, 25, variant=variant)
             torch.cuda.synchronize()
@@ -35,4 +35,4 @@ for code, ebn0 in CASES:
                 code.decode_ms_batch(l, 25, variant=variant)
             b.record(); torch.cuda.synchronize()
             t[name] = a.elapsed_time(b) / reps * 1e3
-        print(f"   {groups:6d} {t['old']:10.1f} {t['bs']:10.1f}   {'bit-sliced' if t['bs'] < t['old'] else 'f32-pipe'}", flush=True)
+        print(f"   {groups:6d} {t['old']:10.1f} {t['bs']:10.1f} {t['ls']:10.1f}   {'bit-sliced' if t['bs'] < t['old'] else 'f32-pipe'}", flush=True)
