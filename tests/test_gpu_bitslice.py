@@ -171,3 +171,40 @@ def test_slot_refill_hands_out_every_frame_exactly_once(code):
     assert all(bool((x == y).all()) for x, y in zip(a, b_))
     oc, ic, kc, _ = oracle.decode_ms_batch(code, llrs[:256], 25)
     assert (a[0][:256].cpu().numpy() == oc).all() and (a[1][:256].cpu().numpy() == ic).all() and (a[2][:256].cpu().numpy() == kc).all()
+
+
+@pytest.mark.parametrize("code", [LDPCCode.TM1536, LDPCCode.TM1280], ids=lambda c: c.name)
+def test_slot_refill_on_concurrent_streams(code):
+    """Two host threads, a stream each, launching the slot-refill kernel back to back on batches of different sizes at the same time:
+    every stream has a queue word of its own (claim_counter), which must be back at zero for the stream's next launch whatever the other
+    stream is doing.  Results equal the lockstep kernel's, launch by launch."""
+    import threading
+    rng = np.random.default_rng(78)
+    hi = 1.5 if code is LDPCCode.TM1280 else 0.0
+    llrs = np.concatenate([oracle.awgn_llrs(code, rng, 700, e, np.int8, scale=8.0, lim=31)[0] for e in (3.0 + hi, 1.0, 5.0 + hi)])
+    rng.shuffle(llrs)
+    dev_llrs = torch.from_numpy(np.tile(llrs, (10, 1))).cuda()                      # 21 000 frames: more than the resident slots
+    sizes = (21000, 17, 4099, 1, 20999, 333)
+    ref = {n: [t.cpu().numpy() for t in code.decode_ms_batch(dev_llrs[:n], 25, variant=BS | 256)] for n in sizes}
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(order):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(6):
+                    for n in order:
+                        got = code.decode_ms_batch(dev_llrs[:n], 25, variant=BS)
+                        st.synchronize()
+                        if not all((a == b.cpu().numpy()).all() for a, b in zip(ref[n], got)):
+                            errors.append((n, rep))
+        except Exception as e:                                                        # noqa: BLE001 -- reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(o,)) for o in (sizes, sizes[::-1])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
