@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "codes.hpp"
+#include "notify.hpp"
 
 #define LDPC_INLINE __attribute__((always_inline))
 
@@ -1704,11 +1705,10 @@ constexpr int min_waves_per_simd()
     return 1;
 }
 
-template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM = selfcorr_med3<CODE, T>(), int NANPASS = 0>
-__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
-decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
-                 uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
-                 uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k)
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM, int NANPASS>
+__device__ __forceinline__ void decode_ms_kernel_main(const T *__restrict__ llrs, uint8_t *__restrict__ output,
+                                                      uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
+                                                      uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k)
 {
     using GEO = Geometry<CODE, T, IPT>;
     constexpr int Q = GEO::M / 4;
@@ -1736,5 +1736,29 @@ decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
     }
 }
 
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM = selfcorr_med3<CODE, T>(), int NANPASS = 0>
+__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
+decode_ms_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
+                 uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
+                 uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k)
+{
+    decode_ms_kernel_main<CODE, T, IPT, PF, LEAN, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k);
+}
+
+// The same kernel for the ONE-WORKGROUP launches of single-frame host calls (notify.hpp): two more arguments and a completion ticket
+// stored at the end.  A kernel of its own, not an argument of decode_ms_kernel: the two arguments alone cost the metric kernel 0.9 %
+// (profiles/r06_kbench/launch_floor.txt); built for the codes of up to 2 048 bits, where a synchronisation is a fifth of a call.
+template <int CODE> constexpr bool notify_kernel_built() { return CODES[CODE].n <= 2048; }
+
+template <int CODE, class T, int IPT, bool PF, int LEAN, int FORM = selfcorr_med3<CODE, T>(), int NANPASS = 0>
+__global__ void __launch_bounds__((Geometry<CODE, T, IPT>::WG), (min_waves_per_simd<CODE, T, IPT, LEAN>()))
+decode_ms_notify_kernel(const T *__restrict__ llrs, uint8_t *__restrict__ output,
+                        uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
+                        uint32_t batch, uint32_t maxiters, float nocap_limit, uint32_t *claim, uint32_t claim_k,
+                        uint32_t *notify, uint32_t notify_ticket)
+{
+    decode_ms_kernel_main<CODE, T, IPT, PF, LEAN, FORM, NANPASS>(llrs, output, iters_out, success_out, batch, maxiters, nocap_limit, claim, claim_k);
+    notify_done(notify, notify_ticket);
+}
 
 }  // namespace ldpc

@@ -185,6 +185,15 @@ hipError_t launch_cfg_form(const T *llrs, uint8_t *output, uint32_t *iters, uint
         grid = resident < (groups + 63) / 64 ? resident : (groups + 63) / 64;
     }
     constexpr bool clamp_form = std::is_same_v<T, float> && FORM == 2;
+    if constexpr (NANPASS == 0 && notify_kernel_built<CODE>()) {        // (a two-pass decode is two launches: never)
+        uint32_t *notify = nullptr, notify_ticket = 0;
+        if (take_notify(grid, notify, notify_ticket)) {
+            hipLaunchKernelGGL((decode_ms_notify_kernel<CODE, T, IPT, PF, LEAN, FORM, NANPASS>), dim3(1), dim3(GEO::WG), 0, stream,
+                               llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim, (uint32_t)K,
+                               notify, notify_ticket);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((decode_ms_kernel<CODE, T, IPT, PF, LEAN, FORM, NANPASS>), dim3((unsigned)grid), dim3(GEO::WG), 0, stream,
                        llrs, output, iters, success, (uint32_t)batch, maxiters, nocap_limit_for(maxiters, clamp_form), claim, (uint32_t)K);
     return hipGetLastError();

@@ -8,7 +8,8 @@ import labrador_ldpc_amd as la
 from labrador_ldpc_amd import LDPCCode
 import oracle
 
-mode = "copies (LABRADOR_LDPC_HIP_NO_DIRECT)" if os.environ.get("LABRADOR_LDPC_HIP_NO_DIRECT") else "direct"
+mode = "copies (LABRADOR_LDPC_HIP_NO_DIRECT)" if os.environ.get("LABRADOR_LDPC_HIP_NO_DIRECT") else \
+       "direct, hipStreamSynchronize (LABRADOR_LDPC_HIP_NO_NOTIFY)" if os.environ.get("LABRADOR_LDPC_HIP_NO_NOTIFY") else "direct, completion ticket"
 print(f"single-frame calls, {mode}: us per call (median of 5 x 400 calls), results checked against the CPU oracle")
 rng = np.random.default_rng(5)
 for code, ebn0 in ((LDPCCode.TC128, 3.0), (LDPCCode.TC512, 3.0), (LDPCCode.TM1280, 4.0), (LDPCCode.TM2048, 2.5), (LDPCCode.TM5120, 4.0), (LDPCCode.TM8192, 2.0)):

@@ -226,3 +226,37 @@ def test_device_batches_larger_than_one_launch_are_sliced(monkeypatch):
         rx[:, 1] ^= 0x08
         o_b, i_b, k_b = code.decode_bf_batch(rx, 30)
         assert bool((k_b == 1).all()) and torch.equal(o_b[:, : code.n() // 8], cws)
+
+
+def test_single_frame_calls_with_and_without_the_completion_ticket():
+    """The reference-shaped single-frame entries on the small codes do not synchronise their stream: the kernel (its notifying twin,
+    csrc/notify.hpp) stores the call's ticket into pinned memory and the calling thread spins on it.  Hundreds of calls in a row, of
+    codes and types whose calls are notified (TC128 ... TM2048 with once-read LLRs) interleaved with calls that are not (larger codes;
+    the register-lean f32 kernels, whose input is copied; two frames per call), must return what the oracle does -- the ticket of call
+    k must never be taken for call k + 1's -- and the same with LABRADOR_LDPC_HIP_NO_NOTIFY=1 in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(91)
+    jobs = []
+    for code, dtype, ebn0 in ((LDPCCode.TC128, np.float32, 3.0), (LDPCCode.TC512, np.int8, 3.0), (LDPCCode.TM2048, np.float32, 2.0),
+                              (LDPCCode.TM1280, np.float32, 3.5), (LDPCCode.TM5120, np.int8, 3.5), (LDPCCode.TC256, np.float64, 3.0),
+                              (LDPCCode.TM1536, np.int16, 2.5), (LDPCCode.TM8192, np.float32, 2.0)):
+        llrs, _ = oracle.awgn_llrs(code, rng, 6, ebn0, dtype)
+        jobs.append((code, llrs, oracle.decode_ms_batch(code, llrs, 30)))
+    for rep in range(40):
+        for code, llrs, (oc, ic, kc, _) in jobs:
+            f = (rep * 5 + int(code)) % 6
+            out = np.full(code.output_len(), 0xEE, np.uint8)
+            ok, iters = code.decode_ms(llrs[f], out, maxiters=30)
+            assert bool(ok) == bool(kc[f]) and (out == oc[f]).all() and (not ok or iters == ic[f]), (code.name, rep, f)
+        if rep % 7 == 3:                                     # a two-frame host batch in between: one launch, not notified
+            code, llrs, (oc, ic, kc, _) = jobs[rep % len(jobs)]
+            o, i, k = code.decode_ms_batch(llrs[:2], 30)
+            assert (o == oc[:2]).all() and (i == ic[:2]).all() and (k == kc[:2]).all()
+    if os.environ.get("LABRADOR_LDPC_HIP_NO_NOTIFY"):
+        return
+    env = dict(os.environ, LABRADOR_LDPC_HIP_NO_NOTIFY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__ + "::test_single_frame_calls_with_and_without_the_completion_ticket"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -19,4 +19,5 @@ build/ub/wide_rate > $O/wide_rate.txt 2>&1                               # f64 /
 python3 tools/wide_types.py 32768 TM8192 TM2048 2>&1 | grep -v amdgpu.ids > $O/wide_types.txt
 cc -std=c11 -O1 -pthread -Iinclude tests/c/threads_single_frame.c -Llabrador_ldpc_amd -llabrador_ldpc_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/labrador_ldpc_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/thr &&
   (for n in 1 4 16; do /tmp/thr $n 2000 2:0; done; for n in 1 16; do /tmp/thr $n 500 8:0; done; /tmp/thr 16 540) > $O/single_frame_threads.txt 2>&1
+python3 tests/soak/single_frame_latency.py 2>&1 | grep -v amdgpu.ids > $O/single_frame_latency.txt   # per-call latency of the reference-shaped entries
 tail -2 $O/big_soak_x4.txt; tail -1 $O/bs_soak_x8.txt; tail -3 $O/rates_all_codes.txt; tail -2 $O/expected_jobs_check.txt
