@@ -20,4 +20,7 @@ python3 tools/wide_types.py 32768 TM8192 TM2048 2>&1 | grep -v amdgpu.ids > $O/w
 cc -std=c11 -O1 -pthread -Iinclude tests/c/threads_single_frame.c -Llabrador_ldpc_amd -llabrador_ldpc_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/labrador_ldpc_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/thr &&
   (for n in 1 4 16; do /tmp/thr $n 2000 2:0; done; for n in 1 16; do /tmp/thr $n 500 8:0; done; /tmp/thr 16 540) > $O/single_frame_threads.txt 2>&1
 python3 tests/soak/single_frame_latency.py 2>&1 | grep -v amdgpu.ids > $O/single_frame_latency.txt   # per-call latency of the reference-shaped entries
+cc -std=c11 -O2 -Iinclude tools/ubench/single_frame_latency.c -Llabrador_ldpc_amd -llabrador_ldpc_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/labrador_ldpc_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/sfl &&
+  (/tmp/sfl; echo "-- LABRADOR_LDPC_HIP_NO_NOTIFY=1"; LABRADOR_LDPC_HIP_NO_NOTIFY=1 /tmp/sfl) > $O/single_frame_latency_c.txt 2>&1    # ... from C, with and without the completion ticket
+python3 tests/soak/refill_fuzz.py 300 2>&1 | grep -v amdgpu.ids > $O/refill_fuzz.txt                  # the slot-refill kernels on random batch sizes / caps / streams
 tail -2 $O/big_soak_x4.txt; tail -1 $O/bs_soak_x8.txt; tail -3 $O/rates_all_codes.txt; tail -2 $O/expected_jobs_check.txt
