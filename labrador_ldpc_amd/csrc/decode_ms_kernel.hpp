@@ -761,6 +761,13 @@ LDPC_DEV int pi_dev(int i, int j)
 // kernel that cannot afford that (the register-lean f32 one: two_pass_nan() in decode_ms_launch.hpp): pass 1 decodes as if no
 // LLR were a NaN and MARKS the codewords that have one (iters_out = NAN_MARK), pass 2 is the in-line kernel over the marked
 // codewords only.
+// Which kernels keep their channel LLRs in LDS instead of registers (one LDS read per variable phase and transmitted block column;
+// the codeword's own lane reads what it wrote: no synchronisation).  TC512 f32: its eight LLR registers are the difference between
+// three and four waves per SIMD (min_waves_per_simd()); 2 KB more LDS per wave, 16 waves x 10 000 bytes = a CU's 160 KB.
+// TC128 / TC256 (148 / 154 registers) are too far from 128 for this to reach it; the narrow types pack their LLRs already.
+template <int CODE, class T, int IPT, int LEAN>
+constexpr bool llr_in_lds() { return CODE == TC512 && std::is_same_v<T, float> && IPT == 1 && LEAN == 0; }
+
 template <int CODE, class T, int IPT, bool PF, int LEAN, int JW, int FORM, int NANPASS = 0>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
                              uint32_t *__restrict__ iters_out, uint8_t *__restrict__ success_out,
@@ -794,7 +801,11 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
     constexpr int FLAG_OFF = INPLACE ? NX * BLK_BYTES + NXC * M * 4 : (NX + NXC) * M * SZ;
     auto hi_off = [](int cs) constexpr { return NX * BLK_BYTES + cs * M * 4; };
     (void)hi_off;
-    constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16;
+    // LLRs in LDS instead of registers (llr_in_lds()): a region of NTX blocks behind the flag words
+    constexpr bool LLR_LDS = llr_in_lds<CODE, T, IPT, LEAN>();
+    constexpr int LLR_OFF = FLAG_OFF + 16;
+    constexpr int GROUP_BYTES = (FLAG_OFF + 8 + 15) / 16 * 16 + (LLR_LDS ? NTX * M * SZ : 0);
+    static_assert(!LLR_LDS || (!INPLACE && !PF && FLAG_OFF % 16 == 0));
     static_assert(!PF || (G == 1 && NT >= 64), "LLR staging needs whole waves per codeword");
     constexpr int TSZ = sizeof(T);
     constexpr int STAGE_BYTES = PF ? N * TSZ : 0;
@@ -998,6 +1009,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                 constexpr int C = decltype(C_)::value;
                 if (PF && staged) llr[S][C] = O::load(*reinterpret_cast<const T *>(stage + (C * M + i) * TSZ));
                 else if constexpr (!LEAN) llr[S][C] = LATE_CANON ? O::keep_raw(lraw[S][C]) : O::load(lraw[S][C]);     // fetched by fetch_llrs()
+                if constexpr (LLR_LDS) lds_store(LLR_OFF + (C * M + i) * SZ, O::store(llr[S][C]));      // (llr[][] dies after the range vote below)
             });
         });
         (void)tu;
@@ -1092,6 +1104,7 @@ LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ o
                         acc = (CANON || NONAN) ? O::keep_raw(x) : (NANVOTE ? O::load_nonan(x) : O::load(x));
                         
                     }
+                    else if constexpr (LLR_LDS) acc = O::from_lds(lds_load(LLR_OFF + (C * M + i) * SZ));
                     else acc = llr[S][C];
                 }
                 if constexpr (INPLACE) {
@@ -1690,6 +1703,9 @@ constexpr int min_waves_per_simd()
     // f64 on TC128 / TC256: 252-253 registers in round 2, 264-268 with round 3's additions -- one wave per SIMD instead of
     // two (694 -> 487, 383 -> 252 M codewords/s); held at 256
     if (sizeof(T) > 4) return (CODE <= TC256 && IPT == 1 && LEAN == 0) ? 2 : 1;
+    // TC512 f32 with its LLRs in LDS (llr_in_lds(): 138 -> 128 registers, four values spilled around the loops, none inside):
+    // four waves per SIMD WITH the wave verdict: +2.5 % at 2 dB (config 2), +4.5 % at 3 dB, +5.5 % at 5 dB (profiles/r06_kbench/tc512_llr_lds.txt)
+    if (llr_in_lds<CODE, T, IPT, LEAN>()) return 4;
     if (LEAN == 1) return 4;
     // i32 on TC512: 127 -> 129 registers with the queue plumbing (which one-wave workgroups never use): held at 128
     if (CODE == TC512 && IPT == 1 && std::is_same_v<T, int32_t>) return 4;
@@ -1713,7 +1729,8 @@ __device__ __forceinline__ void decode_ms_kernel_main(const T *__restrict__ llrs
     using GEO = Geometry<CODE, T, IPT>;
     constexpr int Q = GEO::M / 4;
     constexpr int ESZ = (int)sizeof(typename Ops<T>::E);
-    constexpr int GROUP_BYTES = ((LEAN == 2 ? GEO::NX * GEO::M * ESZ + GEO::NXC * GEO::M * 4 : (GEO::NX + GEO::NXC) * GEO::M * ESZ) + 8 + 15) / 16 * 16;
+    constexpr int GROUP_BYTES = ((LEAN == 2 ? GEO::NX * GEO::M * ESZ + GEO::NXC * GEO::M * 4 : (GEO::NX + GEO::NXC) * GEO::M * ESZ) + 8 + 15) / 16 * 16
+                                + (llr_in_lds<CODE, T, IPT, LEAN>() ? (CODES[CODE].n / GEO::M) * GEO::M * ESZ : 0);
     __shared__ __attribute__((aligned(16))) char lds[GEO::G * GROUP_BYTES];
     __shared__ __attribute__((aligned(16))) char stage[PF ? CODES[CODE].n * sizeof(T) : 16];
     // Waves of a workgroup whose threads own two quarters' worth of indices (TM8192: 1024 threads,

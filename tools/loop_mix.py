@@ -7,6 +7,13 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def loops_of(obj, kernel):
+    return {k: [sp for _, _, sp in v] for k, v in spans_of(obj, kernel).items()}
+
+
+def spans_of(obj, kernel):
+    """{kernel: [(first, last, instructions)]}: positions in the kernel's instruction list, so that nested spans can be told apart
+    (a span that holds another one is not an iteration loop but a path around it: e.g. the jump from a finished codeword's
+    epilogue back into the loop for the next codeword of a one-wave kernel)"""
     tmp = tempfile.mkdtemp()
     subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={tmp}/fat", obj, "/dev/null"])
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
@@ -36,7 +43,7 @@ def loops_of(obj, kernel):
                     continue
                 span = [t for _, t, _ in body[j:i + 1]]
                 if sum(1 for t in span if t.startswith("s_barrier")) == 2:
-                    loops.append(span)
+                    loops.append((j, i, span))
         res[k] = loops
     return res
 
