@@ -764,9 +764,12 @@ LDPC_DEV int pi_dev(int i, int j)
 // Which kernels keep their channel LLRs in LDS instead of registers (one LDS read per variable phase and transmitted block column;
 // the codeword's own lane reads what it wrote: no synchronisation).  TC512 f32: its eight LLR registers are the difference between
 // three and four waves per SIMD (min_waves_per_simd()); 2 KB more LDS per wave, 16 waves x 10 000 bytes = a CU's 160 KB.
-// TC128 / TC256 (148 / 154 registers) are too far from 128 for this to reach it; the narrow types pack their LLRs already.
+// TC128 f32 likewise (148 registers; at 128 it keeps 14 values in scratch around the loops, none inside: +10 % at 2 and 3 dB, +-0 at
+// 5 dB).  TC256 f32 (154 registers, 19 spilled at 128) gains 8 % / 4 % at 2 / 3 dB and LOSES 13 % at 5 dB, where a decode is two
+// iterations and the spills around them weigh: it stays at three waves (profiles/r06_kbench/tc512_llr_lds.txt).  The narrow types
+// pack their LLRs already.
 template <int CODE, class T, int IPT, int LEAN>
-constexpr bool llr_in_lds() { return CODE == TC512 && std::is_same_v<T, float> && IPT == 1 && LEAN == 0; }
+constexpr bool llr_in_lds() { return (CODE == TC512 || CODE == TC128) && std::is_same_v<T, float> && IPT == 1 && LEAN == 0; }
 
 template <int CODE, class T, int IPT, bool PF, int LEAN, int JW, int FORM, int NANPASS = 0>
 LDPC_DEV void decode_ms_body(const T *__restrict__ llrs, uint8_t *__restrict__ output,
@@ -1703,8 +1706,9 @@ constexpr int min_waves_per_simd()
     // f64 on TC128 / TC256: 252-253 registers in round 2, 264-268 with round 3's additions -- one wave per SIMD instead of
     // two (694 -> 487, 383 -> 252 M codewords/s); held at 256
     if (sizeof(T) > 4) return (CODE <= TC256 && IPT == 1 && LEAN == 0) ? 2 : 1;
-    // TC512 f32 with its LLRs in LDS (llr_in_lds(): 138 -> 128 registers, four values spilled around the loops, none inside):
-    // four waves per SIMD WITH the wave verdict: +2.5 % at 2 dB (config 2), +4.5 % at 3 dB, +5.5 % at 5 dB (profiles/r06_kbench/tc512_llr_lds.txt)
+    // TC512 / TC128 f32 with their LLRs in LDS (llr_in_lds(): TC512 138 -> 128 registers, four values spilled around the loops, none
+    // inside): four waves per SIMD WITH the wave verdict: TC512 +2.5 % at 2 dB (config 2), +4.5 % at 3 dB, +5.5 % at 5 dB; TC128 +10 % at
+    // 2 and 3 dB (profiles/r06_kbench/tc512_llr_lds.txt)
     if (llr_in_lds<CODE, T, IPT, LEAN>()) return 4;
     if (LEAN == 1) return 4;
     // i32 on TC512: 127 -> 129 registers with the queue plumbing (which one-wave workgroups never use): held at 128
