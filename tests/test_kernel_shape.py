@@ -222,3 +222,22 @@ def test_experiment_patches_apply_where_they_say_they_do(tmp_path):
         else:
             r = subprocess.run(["git", "apply", "--check", pat], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, f"{os.path.basename(pat)} does not apply: {r.stderr[-600:]}"
+
+
+def test_one_wave_f32_kernels_with_llrs_in_lds_fit_four_waves_per_simd(built_objects):
+    """TC512 f32 (BASELINE config 2) and TC128 f32 keep their channel LLRs in LDS so that the kernel fits 128 registers = four waves per
+    SIMD (csrc/decode_ms_kernel.hpp: llr_in_lds(), round 6: +2.5...5.5 % and +10 %).  What that rests on: at most 128 registers, a
+    handful of values parked in scratch around the loops (TC512 4, TC128 14 -- the loops themselves are checked above), and an LDS
+    block of which sixteen fit a CU's 160 KB.  TC256 f32, which would lose at high SNR, stays above 128."""
+    import kernel_resources
+    seen = {}
+    for obj, dem, v, sp, s, lds, scr in kernel_resources.resources("build/csrc/decode_ms_f32.o"):
+        m = __import__("re").search(r"decode_ms_kernel<(\d), float, 1, false, 0, ", dem)
+        if m:
+            seen.setdefault(int(m.group(1)), []).append((int(v), int(sp), int(lds)))
+    assert set(seen) >= {0, 1, 2}
+    for code, max_spills in ((0, 16), (2, 6)):
+        for v, sp, lds in seen[code]:
+            assert v <= 128 and sp <= max_spills, (code, v, sp)
+            assert 16 * ((lds + 511) // 512 * 512) <= 160 * 1024, (code, lds)
+    assert all(v > 128 for v, _, _ in seen[1])
